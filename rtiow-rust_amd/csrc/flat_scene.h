@@ -1,0 +1,68 @@
+// flat_scene.h -- the HBM layout of a flattened scene ("flat program").
+//
+// The reference walks a recursive `Box<dyn Object>` graph (object.rs:15-40) whose traversal ORDER is
+// observable: hits use strict `<` (object.rs:99,195), the right BVH child is searched with
+// t_max = left.t (bvh.rs:98-102), `And` likewise (object.rs:403-409) and ConstantMedium draws from the
+// RNG during traversal (object.rs:562).  Because that order is always "left subtree, then right
+// subtree" -- never ray dependent -- the whole graph linearises into ONE instruction stream in
+// depth-first order with skip pointers: no traversal stack, exactly the reference's visiting order.
+//
+//   list world  (lib.rs:40-45)      -> its objects' streams back to back
+//   And(a, b)   (object.rs:396-410) -> a's stream, then b's stream
+//   Bvh node    (bvh.rs:84-120)     -> BOX{aabb, skip}, left stream, right stream   (skip = first
+//   Bvh leaf                        -> BOX{aabb, skip}, object's stream              instr. after)
+//   Translate/Scale/RotateY/LinearMove/FlipNormals over a subtree -> PUSH, subtree, POP
+//   Sphere, Translate{Sphere}, FlipNormals thereof -> one fused SPHERE record
+//   Rect<A>, FlipNormals(Rect<A>)                  -> one RECT record
+//   ConstantMedium{boundary = one primitive}       -> MEDIUM record followed by the boundary record
+//
+// Every instruction is 32 bytes = two 16-byte packets, stored as two SoA arrays of uint4
+// (`lo[i]`, `hi[i]`) so that a lane fetches an instruction with two 16-byte loads.
+#pragma once
+#include <stdint.h>
+
+namespace rtg {
+
+enum Op : uint32_t {
+  OP_END = 0,
+  OP_BOX = 1,     // lo = (min.x, min.y, min.z, max.x)  hi = (max.y, max.z, skip_pc, op)
+  OP_SPHERE = 2,  // lo = (off.x, off.y, off.z, radius) hi = (-, -, material, op|flags)
+  OP_RECT = 3,    // lo = (k, r0.start, r0.end, r1.start) hi = (r1.end, -, material, op|flags)
+  OP_PUSH = 4,    // lo = (a, b, c, -)                   hi = (-, -, matching_pop, op|kind)
+  OP_POP = 5,     // lo = (a, b, c, -)                   hi = (-, -, matching_push, op|kind)
+  OP_MEDIUM = 6,  // lo = (density, -, -, -)             hi = (-, -, material, op|flags); boundary = next record
+};
+
+// flag bits in hi.w above the 8-bit opcode
+constexpr uint32_t F_TRANSLATE = 1u << 8;   // SPHERE: origin -= off on the way in, p += off on the way out
+constexpr uint32_t F_FLIP = 1u << 9;        // SPHERE/RECT: normal = -normal (odd number of FlipNormals)
+constexpr uint32_t F_AXIS_SHIFT = 10;       // RECT: bits 10-11 = orthogonal axis (0/1/2)
+constexpr uint32_t F_UNDER_BVH = 1u << 12;  // MEDIUM: lives below a Bvh node (hit-merge rule of bvh.rs:104-112)
+constexpr uint32_t F_BVH_ROOT = 1u << 13;   // BOX: root of an outermost Bvh (a Bvh not nested below another Bvh)
+constexpr uint32_t F_KIND_SHIFT = 8;        // PUSH/POP: bits 8-10 = XformKind
+
+enum XformKind : uint32_t {
+  XF_TRANSLATE = 0,  // (a,b,c) = offset               object.rs:267-283
+  XF_ROTATE_Y = 1,   // (a,b)   = (sin_theta, cos_theta) object.rs:341-370
+  XF_SCALE = 2,      // (a,b,c) = factor               object.rs:301-319
+  XF_MOVE = 3,       // (a,b,c) = motion               object.rs:496-512
+  XF_FLIP = 4,       //                                  object.rs:241-253
+};
+
+constexpr int MAX_XFORM_DEPTH = 4;  // PUSH nesting the kernel's ray stack holds
+
+// Material record, 32 bytes (two uint4): lo = (c.r, c.g, c.b, param) hi = (texture, -, -, kind|texkind<<8)
+//   Lambertian / Isotropic: c = albedo when the texture is constant, else `texture` indexes tex[]
+//   Metal: c = albedo, param = fuzz;  Dielectric: param = ref_idx
+//   DiffuseLight: c = emission when constant, param = brightness
+enum MatKind : uint32_t { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_DIFFUSE_LIGHT = 3, MAT_ISOTROPIC = 4 };
+enum TexKind : uint32_t { TEX_CONSTANT = 0, TEX_CHECKER = 1, TEX_PERLIN = 2 };
+// Texture record, 32 bytes: lo = (r, g, b, scale) hi = (t0, t1, -, kind)
+
+// Feature bits of a flattened scene: select the kernel instantiation (lean book-1 path vs full path)
+constexpr uint32_t FEAT_XFORM = 1u;    // PUSH/POP present
+constexpr uint32_t FEAT_MEDIUM = 2u;   // MEDIUM present
+constexpr uint32_t FEAT_RECT = 4u;     // RECT present
+constexpr uint32_t FEAT_TEXTURE = 8u;  // a non-constant texture is referenced
+
+}  // namespace rtg

@@ -1,0 +1,197 @@
+// rt_device.h -- scalar building blocks of the hot path as gfx950 device code:
+//   V3 arithmetic in the reference's exact operation order (src/vec3.rs),
+//   the per-(pixel,sample) counter RNG (Philox4x32-10) with rand-0.6.5's float conversions,
+//   and the libm restatements (ln / powf(.,5) / sin) that must agree bit-for-bit with the CPU side.
+//
+// Compile with -ffp-contract=off: rustc never fuses a*b+c, hipcc would (v_fmac_f32).  f32 divide and
+// sqrt stay correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt is the hipcc default).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RT_DEV __device__ __forceinline__
+
+namespace rtg {
+
+struct V3 {
+  float x, y, z;
+};
+
+RT_DEV V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+RT_DEV V3 splat(float s) { return V3{s, s, s}; }                                   // vec3.rs:106
+RT_DEV V3 vadd(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }          // vec3.rs:155
+RT_DEV V3 vsub(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }          // vec3.rs:175
+RT_DEV V3 vmul(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }          // vec3.rs:115
+RT_DEV V3 vdiv(V3 a, V3 b) { return V3{a.x / b.x, a.y / b.y, a.z / b.z}; }          // vec3.rs:135
+RT_DEV V3 smul(float s, V3 v) { return V3{s * v.x, s * v.y, s * v.z}; }             // vec3.rs:125
+RT_DEV V3 sdiv(V3 v, float s) { return V3{v.x / s, v.y / s, v.z / s}; }             // vec3.rs:145
+RT_DEV V3 vneg(V3 v) { return V3{-v.x, -v.y, -v.z}; }                               // vec3.rs:185
+RT_DEV float vdot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }       // vec3.rs:43,100
+RT_DEV float vlen(V3 a) { return __builtin_sqrtf(vdot(a, a)); }                     // vec3.rs:59
+RT_DEV V3 vunit(V3 a) { return sdiv(a, vlen(a)); }                                  // vec3.rs:66
+RT_DEV float vget(V3 v, uint32_t axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
+
+// Rust f32::max / f32::min: NaN-ignoring (maxnum); lowers to v_max_f32 / v_min_f32 (IEEE mode).
+RT_DEV float rs_max(float a, float b) { return __builtin_fmaxf(a, b); }
+RT_DEV float rs_min(float a, float b) { return __builtin_fminf(a, b); }
+
+// vec3.rs:313  v - ((2*(v.n)) * n)
+RT_DEV V3 reflect(V3 v, V3 n) { return vsub(v, smul(2.f * vdot(v, n), n)); }
+
+constexpr float F32_MAX = 3.402823466e+38f;
+
+// ---- libm restatements (same algorithms as oracle/rto_core.hpp; parity tests compare them) ------
+struct LogfEntry {
+  double invc, logc;
+};
+__device__ const LogfEntry kLogfTable[128] = {
+#include "rt_logf_table.inc"
+};
+
+// f32::ln (object.rs:562): table (128 intervals, OFF = 0x3f328000 puts 1.0 mid-interval with c = 1)
+// + degree-6 log1p polynomial, all in f64, one final rounding to f32.
+RT_DEV float rt_logf(float x) {
+  uint32_t ix = __float_as_uint(x);
+  if (ix == 0u || ix == 0x80000000u) return -__builtin_inff();
+  if (ix >= 0x7f800000u) {
+    if (ix == 0x7f800000u) return x;
+    return __builtin_nanf("");
+  }
+  int sub = 0;
+  if (ix < 0x00800000u) {
+    ix = __float_as_uint(x * 8388608.0f);
+    sub = 23;
+  }
+  uint32_t tmp = ix - 0x3f328000u;
+  int k = ((int32_t)tmp >> 23) - sub;
+  uint32_t i = (tmp >> 16) & 127u;
+  uint32_t iz = ix - (tmp & 0xff800000u);
+  double z = (double)__uint_as_float(iz);
+  double r = z * kLogfTable[i].invc - 1.0;
+  double y0 = (double)k * 0x1.62e42fefa39efp-1 + kLogfTable[i].logc;
+  double p = -1.0 / 6.0;
+  p = p * r + 0.2;
+  p = p * r + -0.25;
+  p = p * r + (1.0 / 3.0);
+  p = p * r + -0.5;
+  double r2 = r * r;
+  double y = y0 + (r + r2 * p);
+  return (float)y;
+}
+
+// f32::powf(x, 5.) of schlick (material.rs:145): exact-ish f64 products, one rounding.
+RT_DEV float rt_pow5f(float x) {
+  double d = (double)x;
+  double d2 = d * d;
+  double d4 = d2 * d2;
+  return (float)(d4 * d);
+}
+
+// f32::sin of the checker texture (texture.rs:14): f64 Cody-Waite + Taylor kernels.
+RT_DEV float rt_sinf(float x) {
+  if (!(__builtin_fabsf(x) <= 3.0e38f)) return __builtin_nanf("");
+  double y = (double)x;
+  double n = __builtin_rint(y * 0x1.45f306dc9c883p-1);
+  double r = (y - n * 0x1.921fb544p+0) - n * 0x1.0b4611a626331p-34;
+  double r2 = r * r;
+  int q = (int)((long long)n & 3);
+  double ps = -1.0 / 1307674368000.0;
+  ps = ps * r2 + 1.0 / 6227020800.0;
+  ps = ps * r2 + -1.0 / 39916800.0;
+  ps = ps * r2 + 1.0 / 362880.0;
+  ps = ps * r2 + -1.0 / 5040.0;
+  ps = ps * r2 + 1.0 / 120.0;
+  ps = ps * r2 + -1.0 / 6.0;
+  double s = r + r * (r2 * ps);
+  double pc = 1.0 / 20922789888000.0;
+  pc = pc * r2 + -1.0 / 87178291200.0;
+  pc = pc * r2 + 1.0 / 479001600.0;
+  pc = pc * r2 + -1.0 / 3628800.0;
+  pc = pc * r2 + 1.0 / 40320.0;
+  pc = pc * r2 + -1.0 / 720.0;
+  pc = pc * r2 + 1.0 / 24.0;
+  double c = (1.0 - 0.5 * r2) + (r2 * r2) * pc;
+  double v = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
+  return (float)v;
+}
+
+// ---- counter RNG ---------------------------------------------------------------------------------
+// Determinism contract: one Philox4x32-10 stream per (seed, pixel, sample); key = seed,
+// counter = (block, sample, pixel, 0); each block hands out its 4 words in order.
+struct SampleRng {
+  uint32_t k0, k1, sample, pixel, blk;
+  uint32_t b0, b1, b2, b3;  // unread words of the current block, b0 next
+  uint32_t left;            // words left in b0..b3
+  uint32_t draws;
+
+  RT_DEV void init(uint64_t seed, uint32_t pixel_, uint32_t sample_) {
+    k0 = (uint32_t)seed;
+    k1 = (uint32_t)(seed >> 32);
+    pixel = pixel_;
+    sample = sample_;
+    blk = 0;
+    left = 0;
+    draws = 0;
+  }
+  RT_DEV void refill() {
+    uint32_t c0 = blk, c1 = sample, c2 = pixel, c3 = 0u;
+    uint32_t key0 = k0, key1 = k1;
+#pragma unroll
+    for (int round = 0; round < 10; round++) {
+      uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+      uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+      uint32_t n0 = hi1 ^ c1 ^ key0;
+      uint32_t n2 = hi0 ^ c3 ^ key1;
+      c0 = n0;
+      c1 = lo1;
+      c2 = n2;
+      c3 = lo0;
+      key0 += 0x9E3779B9u;
+      key1 += 0xBB67AE85u;
+    }
+    b0 = c0, b1 = c1, b2 = c2, b3 = c3;
+    blk++;
+    left = 4;
+  }
+  RT_DEV uint32_t next_u32() {
+    if (left == 0) refill();
+    uint32_t r = b0;
+    b0 = b1, b1 = b2, b2 = b3;
+    left--;
+    draws++;
+    return r;
+  }
+  // rand 0.6.5 Standard for f32: (u32 >> 8) * 2^-24
+  RT_DEV float gen_f32() { return (float)(next_u32() >> 8) * (1.0f / 16777216.0f); }
+  // rand 0.6.5 UniformFloat::sample_single (camera.rs:55)
+  RT_DEV float gen_range(float low, float high) {
+    float scale = high - low;
+    for (;;) {
+      float value1_2 = __uint_as_float((next_u32() >> 9) | 0x3f800000u);
+      float res = (value1_2 - 1.0f) * scale + low;
+      if (res < high) return res;
+    }
+  }
+};
+
+// vec3.rs:19-26
+RT_DEV V3 in_unit_sphere(SampleRng& rng) {
+  for (;;) {
+    float a = rng.gen_f32();
+    float b = rng.gen_f32();
+    float c = rng.gen_f32();
+    V3 v = vsub(smul(2.f, mk(a, b, c)), splat(1.f));
+    if (vdot(v, v) < 1.f) return v;
+  }
+}
+// vec3.rs:32-39
+RT_DEV V3 in_unit_disc(SampleRng& rng) {
+  for (;;) {
+    float a = rng.gen_f32();
+    float b = rng.gen_f32();
+    V3 v = vsub(smul(2.f, mk(a, b, 0.f)), mk(1.f, 1.f, 0.f));
+    if (vdot(v, v) < 1.f) return v;
+  }
+}
+
+}  // namespace rtg

@@ -1,0 +1,640 @@
+// rtg_api.hip -- kernels + the C ABI of include/rtiow_gpu.h (librtiow_gpu.so).
+//
+// There is no CPU fallback anywhere in this file: without a HIP device every compute entry point
+// returns RTG_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rtiow_gpu.h"
+#include "rt_trace.h"
+#include "scene_builder.h"
+
+using namespace rtg;
+
+// ===================================================================================================
+// Kernels
+// ===================================================================================================
+constexpr uint32_t FEAT_ALL = FEAT_XFORM | FEAT_MEDIUM | FEAT_RECT | FEAT_TEXTURE;
+
+__device__ __forceinline__ void flush_counts(const Counts& c, uint32_t draws, unsigned long long* g) {
+  // one atomic per counter per wave would be nicer; the instrumented variant is not the timed one
+  atomicAdd(&g[0], (unsigned long long)c.aabb);
+  atomicAdd(&g[1], (unsigned long long)c.prim);
+  atomicAdd(&g[2], (unsigned long long)c.shaded);
+  atomicAdd(&g[3], (unsigned long long)c.rays);
+  atomicAdd(&g[4], (unsigned long long)draws);
+}
+
+// par_cast (lib.rs:363-376): one lane owns one pixel and folds its ns samples IN ORDER
+// (iter::Sum is a left fold from (0,0,0), vec3.rs:195-203), then divides by ns.
+// Block = 16x16 pixels, each wave an 8x8 sub-tile (primary rays of a wave stay coherent).
+template <uint32_t FEAT, bool COUNT>
+__global__ __launch_bounds__(256) void render_kernel(DevScene sc, DevCamera cam, DevParams P, float* out,
+                                                     unsigned long long* counters) {
+  const uint32_t nbx = (P.nx + 15u) / 16u;
+  const uint32_t bx = blockIdx.x % nbx, by = blockIdx.x / nbx;
+  const uint32_t tiles_x = (P.nx + P.tile_w - 1u) / P.tile_w;
+  const uint32_t tile = ((by * 16u) / P.tile_h) * tiles_x + (bx * 16u) / P.tile_w;
+  if (tile % P.nranks != P.rank) return;
+  const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+  const uint32_t x = bx * 16u + (w & 1u) * 8u + (l & 7u);
+  const uint32_t row = by * 16u + (w >> 1) * 8u + (l >> 3);
+  if (x >= P.nx || row >= P.ny) return;
+  const uint32_t y = P.ny - 1u - row;  // lib.rs:328: row 0 is y = ny-1
+  Counts cnt = {0, 0, 0, 0};
+  uint32_t total_draws = 0;
+  V3 col = mk(0.f, 0.f, 0.f);
+  for (uint32_t s = 0; s < P.ns; s++) {
+    uint32_t bounces, draws;
+    V3 c = sample_color<FEAT, COUNT>(sc, cam, P, x, y, s, cnt, bounces, draws);
+    col = vadd(col, c);
+    if (COUNT) total_draws += draws;
+  }
+  col = sdiv(col, (float)P.ns);  // lib.rs:374
+  float* o = out + 3ull * ((size_t)row * P.nx + x);
+  o[0] = col.x, o[1] = col.y, o[2] = col.z;
+  if (COUNT) flush_counts(cnt, total_draws, counters);
+}
+
+template <uint32_t FEAT>
+__global__ void debug_hit_top_kernel(DevScene sc, uint32_t n, const float* rays, uint32_t seed_lo, uint32_t seed_hi,
+                                     float t_near, float* out, uint32_t* out_mat) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* r = rays + 7ull * i;
+  SampleRng rng;
+  rng.init(((uint64_t)seed_hi << 32) | seed_lo, i, 0);
+  HitRec h;
+  Counts cnt = {0, 0, 0, 0};
+  bool hit = hit_top<FEAT, false>(sc, mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5]), r[6], t_near, rng, h, cnt);
+  float* o = out + 8ull * i;
+  o[0] = hit ? 1.f : 0.f;
+  o[1] = hit ? h.t : 0.f;
+  o[2] = hit ? h.p.x : 0.f, o[3] = hit ? h.p.y : 0.f, o[4] = hit ? h.p.z : 0.f;
+  o[5] = hit ? h.n.x : 0.f, o[6] = hit ? h.n.y : 0.f, o[7] = hit ? h.n.z : 0.f;
+  out_mat[i] = hit ? h.mat : 0xffffffffu;
+}
+
+template <uint32_t FEAT>
+__global__ void debug_samples_kernel(DevScene sc, DevCamera cam, DevParams P, uint32_t n, const uint32_t* xs,
+                                     const uint32_t* ys, const uint32_t* ss, float* out_rgb, uint32_t* out_info) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Counts cnt = {0, 0, 0, 0};
+  uint32_t bounces = 0, draws = 0;
+  V3 c = sample_color<FEAT, true>(sc, cam, P, xs[i], ys[i], ss[i], cnt, bounces, draws);
+  out_rgb[3 * i] = c.x, out_rgb[3 * i + 1] = c.y, out_rgb[3 * i + 2] = c.z;
+  out_info[4 * i] = bounces, out_info[4 * i + 1] = draws, out_info[4 * i + 2] = cnt.aabb, out_info[4 * i + 3] = cnt.prim;
+}
+
+__global__ void debug_math_kernel(int op, size_t n, const float* in, const float* in2, float* out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x = in[i];
+  float r;
+  switch (op) {
+    case 0: r = rt_logf(x); break;
+    case 1: r = rt_pow5f(x); break;
+    case 2: r = rt_sinf(x); break;
+    case 3: r = __builtin_sqrtf(x); break;
+    case 4: r = 1.f / x; break;
+    default: r = x / in2[i]; break;
+  }
+  out[i] = r;
+}
+
+// ===================================================================================================
+// Host side
+// ===================================================================================================
+namespace {
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+  return fail(RTG_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                   \
+  do {                                                  \
+    hipError_t e_ = (expr);                             \
+    if (e_ != hipSuccess) return hip_fail(e_, #expr);   \
+  } while (0)
+}  // namespace
+
+struct rtg_builder {
+  SceneBuilder sb;
+};
+
+struct rtg_scene {
+  int device = 0;
+  DevScene dev{};
+  uint32_t features = 0;
+  uint32_t n_prog = 0, n_mat = 0, n_tex = 0;
+  uint64_t bytes = 0;
+  void* buffers[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  unsigned long long* d_counters = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+template <bool COUNT>
+static void launch_render(const rtg_scene* s, const DevCamera& cam, const DevParams& d, float* d_out,
+                          hipStream_t stream) {
+  uint32_t nbx = (d.nx + 15) / 16, nby = (d.ny + 15) / 16;
+  dim3 grid(nbx * nby), block(256);
+  if (s->features == 0)
+    hipLaunchKernelGGL((render_kernel<0u, COUNT>), grid, block, 0, stream, s->dev, cam, d, d_out, s->d_counters);
+  else
+    hipLaunchKernelGGL((render_kernel<FEAT_ALL, COUNT>), grid, block, 0, stream, s->dev, cam, d, d_out, s->d_counters);
+}
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t n) { return hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)); }
+};
+
+extern "C" {
+
+const char* rtg_version(void) { return "rtiow-rust_amd 0.1 (gfx950 HIP; flat-program megakernel)"; }
+const char* rtg_last_error(void) { return g_err.c_str(); }
+
+int rtg_device_count(int* n) {
+  if (!n) return fail(RTG_ERR_INVALID, "null argument");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) {
+    *n = 0;
+    return hip_fail(e, "hipGetDeviceCount");
+  }
+  *n = c;
+  return RTG_OK;
+}
+
+int rtg_builder_create(rtg_builder** out) {
+  if (!out) return fail(RTG_ERR_INVALID, "null argument");
+  *out = new rtg_builder();
+  return RTG_OK;
+}
+void rtg_builder_destroy(rtg_builder* b) { delete b; }
+
+// ---- textures ------------------------------------------------------------------------------------
+static rtg_id bad(const char* msg) {
+  fail(RTG_ERR_INVALID, msg);
+  return RTG_INVALID_ID;
+}
+
+rtg_id rtg_texture_constant(rtg_builder* b, const float rgb[3]) {
+  if (!b || !rgb) return bad("null argument");
+  HostTexture t;
+  t.kind = TEX_CONSTANT;
+  t.rgb[0] = rgb[0], t.rgb[1] = rgb[1], t.rgb[2] = rgb[2];
+  b->sb.textures.push_back(t);
+  return (rtg_id)b->sb.textures.size() - 1;
+}
+rtg_id rtg_texture_checker(rtg_builder* b, rtg_id t0, rtg_id t1) {
+  if (!b) return bad("null argument");
+  if (t0 >= b->sb.textures.size() || t1 >= b->sb.textures.size()) return bad("checker: bad texture handle");
+  HostTexture t;
+  t.kind = TEX_CHECKER;
+  t.t0 = t0, t.t1 = t1;
+  b->sb.textures.push_back(t);
+  return (rtg_id)b->sb.textures.size() - 1;
+}
+rtg_id rtg_texture_perlin(rtg_builder* b, float scale) {
+  if (!b) return bad("null argument");
+  if (!b->sb.has_perlin) return bad("perlin: call rtg_builder_set_perlin_tables first");
+  HostTexture t;
+  t.kind = TEX_PERLIN;
+  t.scale = scale;
+  b->sb.textures.push_back(t);
+  return (rtg_id)b->sb.textures.size() - 1;
+}
+int rtg_builder_set_perlin_tables(rtg_builder* b, const float vecs[768], const uint8_t px[256],
+                                  const uint8_t py[256], const uint8_t pz[256]) {
+  if (!b || !vecs || !px || !py || !pz) return fail(RTG_ERR_INVALID, "null argument");
+  for (int i = 0; i < 256; i++) {
+    b->sb.perlin_vecs[4 * i] = vecs[3 * i], b->sb.perlin_vecs[4 * i + 1] = vecs[3 * i + 1];
+    b->sb.perlin_vecs[4 * i + 2] = vecs[3 * i + 2], b->sb.perlin_vecs[4 * i + 3] = 0.f;
+    b->sb.perlin_perm[i] = px[i], b->sb.perlin_perm[256 + i] = py[i], b->sb.perlin_perm[512 + i] = pz[i];
+  }
+  b->sb.has_perlin = true;
+  return RTG_OK;
+}
+
+// ---- materials -----------------------------------------------------------------------------------
+static rtg_id push_material(rtg_builder* b, uint32_t kind, rtg_id tex, const float* albedo, float param) {
+  if (!b) return bad("null argument");
+  HostMaterial m;
+  m.kind = kind;
+  if (tex != RTG_INVALID_ID) {
+    if (tex >= b->sb.textures.size()) return bad("material: bad texture handle");
+    m.tex = tex;
+  }
+  if (albedo) m.albedo[0] = albedo[0], m.albedo[1] = albedo[1], m.albedo[2] = albedo[2];
+  m.param = param;
+  b->sb.materials.push_back(m);
+  return (rtg_id)b->sb.materials.size() - 1;
+}
+rtg_id rtg_material_lambertian(rtg_builder* b, rtg_id albedo) {
+  if (albedo == RTG_INVALID_ID) return bad("material: bad texture handle");
+  return push_material(b, MAT_LAMBERTIAN, albedo, nullptr, 0.f);
+}
+rtg_id rtg_material_metal(rtg_builder* b, const float albedo[3], float fuzz) {
+  if (!albedo) return bad("null argument");
+  return push_material(b, MAT_METAL, RTG_INVALID_ID, albedo, fuzz);
+}
+rtg_id rtg_material_dielectric(rtg_builder* b, float ref_idx) {
+  return push_material(b, MAT_DIELECTRIC, RTG_INVALID_ID, nullptr, ref_idx);
+}
+rtg_id rtg_material_diffuse_light(rtg_builder* b, rtg_id emission, float brightness) {
+  if (emission == RTG_INVALID_ID) return bad("material: bad texture handle");
+  return push_material(b, MAT_DIFFUSE_LIGHT, emission, nullptr, brightness);
+}
+rtg_id rtg_material_isotropic(rtg_builder* b, rtg_id albedo) {
+  if (albedo == RTG_INVALID_ID) return bad("material: bad texture handle");
+  return push_material(b, MAT_ISOTROPIC, albedo, nullptr, 0.f);
+}
+
+// ---- objects -------------------------------------------------------------------------------------
+static rtg_id push_object(rtg_builder* b, const HostObject& o) {
+  if (!b) return bad("null argument");
+  try {
+    return b->sb.add_object(o);
+  } catch (const BuildError& e) {
+    fail(e.code, e.msg);
+    return RTG_INVALID_ID;
+  }
+}
+rtg_id rtg_object_sphere(rtg_builder* b, float radius, rtg_id material) {
+  HostObject o;
+  o.kind = HostObject::SPHERE;
+  o.f[0] = radius;
+  o.mat = material;
+  return push_object(b, o);
+}
+rtg_id rtg_object_rect(rtg_builder* b, int axis, float r0s, float r0e, float r1s, float r1e, float k, rtg_id material) {
+  HostObject o;
+  o.kind = HostObject::RECT;
+  o.axis = axis;
+  o.f[0] = k, o.f[1] = r0s, o.f[2] = r0e, o.f[3] = r1s, o.f[4] = r1e;
+  o.mat = material;
+  return push_object(b, o);
+}
+static rtg_id wrapper(rtg_builder* b, HostObject::Kind kind, const float* v, rtg_id child) {
+  HostObject o;
+  o.kind = kind;
+  if (v) o.f[0] = v[0], o.f[1] = v[1], o.f[2] = v[2];
+  o.a = child;
+  return push_object(b, o);
+}
+rtg_id rtg_object_flip_normals(rtg_builder* b, rtg_id object) { return wrapper(b, HostObject::FLIP, nullptr, object); }
+rtg_id rtg_object_translate(rtg_builder* b, const float offset[3], rtg_id object) {
+  if (!offset) return bad("null argument");
+  return wrapper(b, HostObject::TRANSLATE, offset, object);
+}
+rtg_id rtg_object_scale(rtg_builder* b, const float factor[3], rtg_id object) {
+  if (!factor) return bad("null argument");
+  return wrapper(b, HostObject::SCALE, factor, object);
+}
+rtg_id rtg_object_rotate_y(rtg_builder* b, float degrees, rtg_id object) {
+  // object.rs:477-484: radians = degrees * PI / 180; sin/cos via the platform libm (host-side setup)
+  float radians = degrees * 3.14159265358979323846f / 180.f;
+  float sc[3] = {sinf(radians), cosf(radians), 0.f};
+  return wrapper(b, HostObject::ROTATE_Y, sc, object);
+}
+rtg_id rtg_object_and(rtg_builder* b, rtg_id o0, rtg_id o1) {
+  HostObject o;
+  o.kind = HostObject::AND;
+  o.a = o0, o.b = o1;
+  return push_object(b, o);
+}
+rtg_id rtg_object_rect_prism(rtg_builder* b, const float p0[3], const float p1[3], rtg_id m) {
+  // object.rs:420-473: And(And(+Z, And(+Y, +X)), And(Flip(-Z), And(Flip(-Y), Flip(-X))))
+  if (!b || !p0 || !p1) return bad("null argument");
+  rtg_id zp = rtg_object_rect(b, 2, p0[0], p1[0], p0[1], p1[1], p1[2], m);
+  rtg_id yp = rtg_object_rect(b, 1, p0[0], p1[0], p0[2], p1[2], p1[1], m);
+  rtg_id xp = rtg_object_rect(b, 0, p0[1], p1[1], p0[2], p1[2], p1[0], m);
+  if (zp == RTG_INVALID_ID || yp == RTG_INVALID_ID || xp == RTG_INVALID_ID) return RTG_INVALID_ID;
+  rtg_id zn = rtg_object_flip_normals(b, rtg_object_rect(b, 2, p0[0], p1[0], p0[1], p1[1], p0[2], m));
+  rtg_id yn = rtg_object_flip_normals(b, rtg_object_rect(b, 1, p0[0], p1[0], p0[2], p1[2], p0[1], m));
+  rtg_id xn = rtg_object_flip_normals(b, rtg_object_rect(b, 0, p0[1], p1[1], p0[2], p1[2], p0[0], m));
+  return rtg_object_and(b, rtg_object_and(b, zp, rtg_object_and(b, yp, xp)),
+                        rtg_object_and(b, zn, rtg_object_and(b, yn, xn)));
+}
+rtg_id rtg_object_linear_move(rtg_builder* b, rtg_id object, const float motion[3]) {
+  if (!motion) return bad("null argument");
+  return wrapper(b, HostObject::MOVE, motion, object);
+}
+rtg_id rtg_object_constant_medium(rtg_builder* b, rtg_id boundary, float density, rtg_id material) {
+  HostObject o;
+  o.kind = HostObject::MEDIUM;
+  o.f[0] = density;
+  o.a = boundary;
+  o.mat = material;
+  return push_object(b, o);
+}
+rtg_id rtg_object_bvh(rtg_builder* b, const rtg_id* objects, size_t n, float e0, float e1) {
+  if (!b || (!objects && n)) return bad("null argument");
+  try {
+    return b->sb.add_bvh(objects, n, e0, e1);
+  } catch (const BuildError& e) {
+    fail(e.code, e.msg);
+    return RTG_INVALID_ID;
+  }
+}
+
+// ---- camera (camera.rs:18-50; host-side setup, tan from the platform libm) ---------------------
+int rtg_camera_look(const float from[3], const float at[3], const float up[3], float fov, float aspect,
+                    float aperture, float focus_dist, float e0, float e1, rtg_camera* out) {
+  if (!from || !at || !up || !out) return fail(RTG_ERR_INVALID, "null argument");
+  auto dot3 = [](const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; };
+  auto unit = [&](float* v) {
+    float len = sqrtf(dot3(v, v));
+    v[0] = v[0] / len, v[1] = v[1] / len, v[2] = v[2] / len;
+  };
+  auto cross3 = [](const float* a, const float* b, float* r) {
+    r[0] = a[1] * b[2] - a[2] * b[1];
+    r[1] = -(a[0] * b[2] - a[2] * b[0]);
+    r[2] = a[0] * b[1] - a[1] * b[0];
+  };
+  float lens_radius = aperture / 2.f;
+  float theta = fov * 3.14159265358979323846f / 180.f;
+  float half_height = tanf(theta / 2.f);
+  float half_width = aspect * half_height;
+  float w[3] = {from[0] - at[0], from[1] - at[1], from[2] - at[2]};
+  unit(w);
+  float u[3], v[3];
+  cross3(up, w, u);
+  unit(u);
+  cross3(w, u, v);
+  float hw_fd = half_width * focus_dist, hh_fd = half_height * focus_dist;
+  float h2 = (2.f * half_width) * focus_dist, v2 = (2.f * half_height) * focus_dist;
+  for (int i = 0; i < 3; i++) {
+    out->origin[i] = from[i];
+    out->lower_left_corner[i] = ((from[i] - hw_fd * u[i]) - hh_fd * v[i]) - focus_dist * w[i];
+    out->horizontal[i] = h2 * u[i];
+    out->vertical[i] = v2 * v[i];
+    out->u[i] = u[i];
+    out->v[i] = v[i];
+  }
+  out->lens_radius = lens_radius;
+  out->exposure_start = e0;
+  out->exposure_end = e1;
+  return RTG_OK;
+}
+
+// ---- scene ---------------------------------------------------------------------------------------
+static int upload(void** dst, const void* src, size_t bytes, uint64_t* total) {
+  size_t alloc = bytes ? bytes : 16;
+  HIP_TRY(hipMalloc(dst, alloc));
+  if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  *total += alloc;
+  return RTG_OK;
+}
+
+void rtg_scene_destroy(rtg_scene* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  for (void* p : s->buffers)
+    if (p) (void)hipFree(p);
+  if (s->d_counters) (void)hipFree(s->d_counters);
+  if (s->ev0) (void)hipEventDestroy(s->ev0);
+  if (s->ev1) (void)hipEventDestroy(s->ev1);
+  delete s;
+}
+
+int rtg_scene_create(rtg_builder* b, const rtg_id* world, size_t n, int device, rtg_scene** out) {
+  if (!b || !out || (!world && n)) return fail(RTG_ERR_INVALID, "null argument");
+  FlatScene fs;
+  try {
+    b->sb.flatten(world, n, &fs);
+  } catch (const BuildError& e) {
+    return fail(e.code, e.msg);
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(RTG_ERR_DEVICE, "no HIP device: the rtiow hot path has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(RTG_ERR_INVALID, "bad device index");
+  HIP_TRY(hipSetDevice(device));
+  rtg_scene* s = new rtg_scene();
+  s->device = device;
+  s->features = fs.features;
+  s->n_prog = (uint32_t)fs.lo.size();
+  s->n_mat = (uint32_t)fs.mat.size() / 2;
+  s->n_tex = (uint32_t)fs.tex.size() / 2;
+  int rc;
+  if ((rc = upload(&s->buffers[0], fs.lo.data(), fs.lo.size() * 16, &s->bytes)) ||
+      (rc = upload(&s->buffers[1], fs.hi.data(), fs.hi.size() * 16, &s->bytes)) ||
+      (rc = upload(&s->buffers[2], fs.mat.data(), fs.mat.size() * 16, &s->bytes)) ||
+      (rc = upload(&s->buffers[3], fs.tex.data(), fs.tex.size() * 16, &s->bytes)) ||
+      (rc = upload(&s->buffers[4], fs.perlin_vecs.data(), sizeof(float) * 1024, &s->bytes)) ||
+      (rc = upload(&s->buffers[5], fs.perlin_perm.data(), 768, &s->bytes))) {
+    rtg_scene_destroy(s);
+    return rc;
+  }
+  s->dev.lo = (const uint4*)s->buffers[0];
+  s->dev.hi = (const uint4*)s->buffers[1];
+  s->dev.mat = (const uint4*)s->buffers[2];
+  s->dev.tex = (const uint4*)s->buffers[3];
+  s->dev.perlin_vecs = (const float4*)s->buffers[4];
+  s->dev.perlin_perm = (const uint8_t*)s->buffers[5];
+  s->dev.n_prog = s->n_prog;
+  if (hipMalloc((void**)&s->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
+      hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
+    rtg_scene_destroy(s);
+    return fail(RTG_ERR_DEVICE, "scene: counter/event allocation failed");
+  }
+  *out = s;
+  return RTG_OK;
+}
+
+int rtg_scene_info(const rtg_scene* s, uint32_t* n_instructions, uint32_t* n_materials, uint32_t* n_textures,
+                   uint64_t* hbm_bytes) {
+  if (!s) return fail(RTG_ERR_INVALID, "null argument");
+  if (n_instructions) *n_instructions = s->n_prog;
+  if (n_materials) *n_materials = s->n_mat;
+  if (n_textures) *n_textures = s->n_tex;
+  if (hbm_bytes) *hbm_bytes = s->bytes;
+  return RTG_OK;
+}
+
+// ---- render --------------------------------------------------------------------------------------
+static DevCamera to_dev(const rtg_camera* c) {
+  DevCamera d;
+  auto v = [](const float* p) { return V3{p[0], p[1], p[2]}; };
+  d.origin = v(c->origin), d.llc = v(c->lower_left_corner), d.horizontal = v(c->horizontal);
+  d.vertical = v(c->vertical), d.u = v(c->u), d.v = v(c->v);
+  d.lens_radius = c->lens_radius, d.e0 = c->exposure_start, d.e1 = c->exposure_end;
+  return d;
+}
+
+static int check_params(const rtg_scene* s, const rtg_camera* camera, const rtg_params* p, DevParams* out) {
+  if (!s || !camera || !p) return fail(RTG_ERR_INVALID, "null argument");
+  if (p->struct_size != sizeof(rtg_params)) return fail(RTG_ERR_INVALID, "rtg_params.struct_size mismatch");
+  if (p->nx == 0 || p->ny == 0 || p->ns == 0) return fail(RTG_ERR_INVALID, "nx, ny, ns must be > 0");
+  if ((uint64_t)p->nx * p->ny > 0xffffffffull) return fail(RTG_ERR_INVALID, "image too large for 32-bit pixel index");
+  if (!(camera->exposure_start < camera->exposure_end))  // camera.rs:55 / rand assert
+    return fail(RTG_ERR_RANGE, "Uniform::sample_single called with low >= high");
+  DevParams d;
+  d.nx = p->nx, d.ny = p->ny, d.ns = p->ns, d.max_bounces = p->max_bounces;
+  d.t_near = p->t_near;
+  d.seed_lo = (uint32_t)p->seed, d.seed_hi = (uint32_t)(p->seed >> 32);
+  d.tile_w = p->tile_w ? p->tile_w : 16u;
+  d.tile_h = p->tile_h ? p->tile_h : 16u;
+  if (d.tile_w % 16u || d.tile_h % 16u) return fail(RTG_ERR_INVALID, "tile_w / tile_h must be multiples of 16");
+  d.nranks = p->nranks ? p->nranks : 1u;
+  d.rank = p->rank;
+  if (d.rank >= d.nranks) return fail(RTG_ERR_INVALID, "rank >= nranks");
+  *out = d;
+  return RTG_OK;
+}
+
+static uint64_t owned_pixels(const DevParams& d) {
+  uint64_t px = 0;
+  uint32_t tiles_x = (d.nx + d.tile_w - 1) / d.tile_w, tiles_y = (d.ny + d.tile_h - 1) / d.tile_h;
+  for (uint32_t ty = 0; ty < tiles_y; ty++)
+    for (uint32_t tx = 0; tx < tiles_x; tx++) {
+      if ((ty * tiles_x + tx) % d.nranks != d.rank) continue;
+      uint32_t w = std::min(d.tile_w, d.nx - tx * d.tile_w), h = std::min(d.tile_h, d.ny - ty * d.tile_h);
+      px += (uint64_t)w * h;
+    }
+  return px;
+}
+
+int rtg_par_cast_device(rtg_scene* s, const rtg_camera* camera, const rtg_params* params, float* d_out,
+                        void* hip_stream, rtg_stats* stats) {
+  DevParams d;
+  int rc = check_params(s, camera, params, &d);
+  if (rc) return rc;
+  if (!d_out) return fail(RTG_ERR_INVALID, "null output");
+  if (stats && stats->struct_size != sizeof(rtg_stats)) return fail(RTG_ERR_INVALID, "rtg_stats.struct_size mismatch");
+  HIP_TRY(hipSetDevice(s->device));
+  hipStream_t stream = (hipStream_t)hip_stream;
+  DevCamera cam = to_dev(camera);
+  bool count = stats && (params->flags & RTG_FLAG_COUNTERS);
+  if (count) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), stream));
+  if (stats) HIP_TRY(hipEventRecord(s->ev0, stream));
+  if (count) launch_render<true>(s, cam, d, d_out, stream);
+  else launch_render<false>(s, cam, d, d_out, stream);
+  HIP_TRY(hipGetLastError());
+  if (stats) {
+    HIP_TRY(hipEventRecord(s->ev1, stream));
+    HIP_TRY(hipEventSynchronize(s->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    stats->kernel_ms = ms;
+    stats->samples = owned_pixels(d) * d.ns;
+    unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (count) HIP_TRY(hipMemcpy(h, s->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+    stats->aabb_tests = h[0], stats->prim_tests = h[1], stats->shaded_hits = h[2], stats->rays = h[3], stats->draws = h[4];
+  }
+  return RTG_OK;
+}
+
+int rtg_par_cast(rtg_scene* s, const rtg_camera* camera, const rtg_params* params, float* out_rgb, rtg_stats* stats) {
+  if (!s || !params || !out_rgb) return fail(RTG_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  size_t bytes = (size_t)params->nx * params->ny * 3 * sizeof(float);
+  float* d_out = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_out, bytes ? bytes : 16));
+  // pixels of other ranks stay as the caller left them
+  hipError_t e = hipMemcpy(d_out, out_rgb, bytes, hipMemcpyHostToDevice);
+  int rc = (e == hipSuccess) ? rtg_par_cast_device(s, camera, params, d_out, nullptr, stats) : hip_fail(e, "hipMemcpy");
+  if (rc == RTG_OK) {
+    e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out_rgb, d_out, bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = hip_fail(e, "render / copy back");
+  }
+  (void)hipFree(d_out);
+  return rc;
+}
+
+// ---- probes --------------------------------------------------------------------------------------
+int rtg_debug_hit_top(rtg_scene* s, size_t n, const float* rays, uint64_t seed, float t_near, float* out,
+                      uint32_t* out_material) {
+  if (!s || !rays || !out || !out_material) return fail(RTG_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  DevBuf<float> d_rays, d_out;
+  DevBuf<uint32_t> d_mat;
+  HIP_TRY(d_rays.alloc(7 * n));
+  HIP_TRY(d_out.alloc(8 * n));
+  HIP_TRY(d_mat.alloc(n));
+  HIP_TRY(hipMemcpy(d_rays.p, rays, 7 * n * sizeof(float), hipMemcpyHostToDevice));
+  dim3 grid((uint32_t)((n + 63) / 64)), block(64);
+  if (n) {
+    if (s->features == 0)
+      hipLaunchKernelGGL((debug_hit_top_kernel<0u>), grid, block, 0, 0, s->dev, (uint32_t)n, d_rays.p, (uint32_t)seed,
+                         (uint32_t)(seed >> 32), t_near, d_out.p, d_mat.p);
+    else
+      hipLaunchKernelGGL((debug_hit_top_kernel<FEAT_ALL>), grid, block, 0, 0, s->dev, (uint32_t)n, d_rays.p,
+                         (uint32_t)seed, (uint32_t)(seed >> 32), t_near, d_out.p, d_mat.p);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, d_out.p, 8 * n * sizeof(float), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_material, d_mat.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return RTG_OK;
+}
+
+int rtg_debug_samples(rtg_scene* s, const rtg_camera* camera, const rtg_params* params, size_t n, const uint32_t* xs,
+                      const uint32_t* ys, const uint32_t* samples, float* out_rgb, uint32_t* out_info) {
+  DevParams d;
+  int rc = check_params(s, camera, params, &d);
+  if (rc) return rc;
+  if (!xs || !ys || !samples || !out_rgb || !out_info) return fail(RTG_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  DevBuf<uint32_t> dx, dy, ds, dinfo;
+  DevBuf<float> drgb;
+  HIP_TRY(dx.alloc(n));
+  HIP_TRY(dy.alloc(n));
+  HIP_TRY(ds.alloc(n));
+  HIP_TRY(dinfo.alloc(4 * n));
+  HIP_TRY(drgb.alloc(3 * n));
+  HIP_TRY(hipMemcpy(dx.p, xs, n * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dy.p, ys, n * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ds.p, samples, n * 4, hipMemcpyHostToDevice));
+  DevCamera cam = to_dev(camera);
+  dim3 grid((uint32_t)((n + 63) / 64)), block(64);
+  if (n) {
+    if (s->features == 0)
+      hipLaunchKernelGGL((debug_samples_kernel<0u>), grid, block, 0, 0, s->dev, cam, d, (uint32_t)n, dx.p, dy.p, ds.p,
+                         drgb.p, dinfo.p);
+    else
+      hipLaunchKernelGGL((debug_samples_kernel<FEAT_ALL>), grid, block, 0, 0, s->dev, cam, d, (uint32_t)n, dx.p, dy.p,
+                         ds.p, drgb.p, dinfo.p);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out_rgb, drgb.p, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_info, dinfo.p, 4 * n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return RTG_OK;
+}
+
+int rtg_debug_math(int device, int op, size_t n, const float* in, const float* in2, float* out) {
+  if (!in || !out || op < 0 || op > 5 || (op == 5 && !in2)) return fail(RTG_ERR_INVALID, "bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(RTG_ERR_DEVICE, "no HIP device");
+  HIP_TRY(hipSetDevice(device));
+  DevBuf<float> di, di2, dout;
+  HIP_TRY(di.alloc(n));
+  HIP_TRY(di2.alloc(n));
+  HIP_TRY(dout.alloc(n));
+  HIP_TRY(hipMemcpy(di.p, in, n * sizeof(float), hipMemcpyHostToDevice));
+  if (in2) HIP_TRY(hipMemcpy(di2.p, in2, n * sizeof(float), hipMemcpyHostToDevice));
+  if (n) hipLaunchKernelGGL(debug_math_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, op, n, di.p, di2.p, dout.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, dout.p, n * sizeof(float), hipMemcpyDeviceToHost));
+  return RTG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,306 @@
+// scene_builder.cpp -- host-side scene graph, Bvh::new, bounding boxes and the flattener.
+// Compiled with -ffp-contract=off: the f32 arithmetic here (boxes, centroids) must round exactly as
+// the reference's would.
+#include "scene_builder.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace rtg {
+
+namespace {
+constexpr float kF32Max = std::numeric_limits<float>::max();
+constexpr uint32_t kNone = 0xffffffffu;
+
+// Rust f32::min / f32::max (NaN-ignoring), used by Aabb::merge (aabb.rs:9-14) and Bvh::new.
+inline float fmin_rs(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a < b ? a : b)); }
+inline float fmax_rs(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a > b ? a : b)); }
+
+Box3 merge(const Box3& p, const Box3& q) {
+  Box3 r;
+  for (int i = 0; i < 3; i++) {
+    r.mn[i] = fmin_rs(p.mn[i], q.mn[i]);
+    r.mx[i] = fmax_rs(p.mx[i], q.mx[i]);
+  }
+  return r;
+}
+
+uint32_t fbits(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  return u;
+}
+
+// object.rs:373-379: rot(c) = (c.(cos,0,sin), c.(0,1,0), c.(-sin,0,cos)), dot = (x*x'+y*y')+z*z'
+void rot_y(const float p[3], float s, float c, float out[3]) {
+  out[0] = (p[0] * c + p[1] * 0.f) + p[2] * s;
+  out[1] = (p[0] * 0.f + p[1] * 1.f) + p[2] * 0.f;
+  out[2] = (p[0] * (-s) + p[1] * 0.f) + p[2] * c;
+}
+}  // namespace
+
+uint32_t SceneBuilder::add_object(const HostObject& o) {
+  auto valid = [&](uint32_t id) { return id < objects.size(); };
+  switch (o.kind) {
+    case HostObject::SPHERE:
+    case HostObject::RECT:
+      if (o.mat >= materials.size()) throw BuildError{-1, "object: bad material handle"};
+      if (o.kind == HostObject::RECT && (o.axis < 0 || o.axis > 2)) throw BuildError{-1, "rect: bad axis"};
+      break;
+    case HostObject::AND:
+      if (!valid(o.a) || !valid(o.b)) throw BuildError{-1, "and: bad object handle"};
+      break;
+    case HostObject::MEDIUM:
+      if (!valid(o.a)) throw BuildError{-1, "constant_medium: bad boundary handle"};
+      if (o.mat >= materials.size()) throw BuildError{-1, "constant_medium: bad material handle"};
+      break;
+    case HostObject::BVH: break;
+    default:
+      if (!valid(o.a)) throw BuildError{-1, "wrapper: bad object handle"};
+  }
+  objects.push_back(o);
+  return (uint32_t)objects.size() - 1;
+}
+
+// Object::bounding_box for every object kind (object.rs:113,220,255,285,321,372,412,514,577; bvh.rs:122)
+Box3 SceneBuilder::bounding_box(uint32_t id, float e0, float e1) const {
+  const HostObject& o = objects[id];
+  Box3 r;
+  switch (o.kind) {
+    case HostObject::SPHERE:
+      for (int i = 0; i < 3; i++) r.mn[i] = -o.f[0], r.mx[i] = o.f[0];
+      return r;
+    case HostObject::RECT: {
+      int o1 = o.axis == 0 ? 1 : 0, o2 = o.axis == 2 ? 1 : 2;
+      r.mn[o.axis] = o.f[0] - 0.0001f;
+      r.mx[o.axis] = o.f[0] + 0.0001f;
+      r.mn[o1] = o.f[1], r.mx[o1] = o.f[2];
+      r.mn[o2] = o.f[3], r.mx[o2] = o.f[4];
+      return r;
+    }
+    case HostObject::FLIP: return bounding_box(o.a, e0, e1);
+    case HostObject::TRANSLATE: {
+      Box3 b = bounding_box(o.a, e0, e1);
+      for (int i = 0; i < 3; i++) r.mn[i] = b.mn[i] + o.f[i], r.mx[i] = b.mx[i] + o.f[i];
+      return r;
+    }
+    case HostObject::SCALE: {
+      Box3 b = bounding_box(o.a, e0, e1);
+      for (int i = 0; i < 3; i++) r.mn[i] = b.mn[i] * o.f[i], r.mx[i] = b.mx[i] * o.f[i];
+      return r;
+    }
+    case HostObject::ROTATE_Y: {
+      Box3 b = bounding_box(o.a, e0, e1);
+      for (int i = 0; i < 3; i++) r.mn[i] = kF32Max, r.mx[i] = -kF32Max;
+      for (int c = 0; c < 8; c++) {  // aabb.rs:29-43: x outermost, z innermost
+        float p[3] = {(c & 4) ? b.mx[0] : b.mn[0], (c & 2) ? b.mx[1] : b.mn[1], (c & 1) ? b.mx[2] : b.mn[2]};
+        float q[3];
+        rot_y(p, o.f[0], o.f[1], q);
+        for (int i = 0; i < 3; i++) r.mn[i] = fmin_rs(r.mn[i], q[i]), r.mx[i] = fmax_rs(r.mx[i], q[i]);
+      }
+      return r;
+    }
+    case HostObject::AND: return merge(bounding_box(o.a, e0, e1), bounding_box(o.b, e0, e1));
+    case HostObject::MOVE: {
+      Box3 b = bounding_box(o.a, e0, e1), s, t;
+      for (int i = 0; i < 3; i++) {
+        s.mn[i] = b.mn[i] + e0 * o.f[i], s.mx[i] = b.mx[i] + e0 * o.f[i];
+        t.mn[i] = b.mn[i] + e1 * o.f[i], t.mx[i] = b.mx[i] + e1 * o.f[i];
+      }
+      return merge(s, t);
+    }
+    case HostObject::MEDIUM: return bounding_box(o.a, e0, e1);
+    default: return bvh_nodes[o.a].box;  // BVH
+  }
+}
+
+// Bvh::new, bvh.rs:22-81.  Widest-axis median split; the reference's sort_unstable_by tie order is
+// rustc-specific, this build's documented tie rule is "stable" (SURVEY.md a17).
+int32_t SceneBuilder::build_bvh(std::vector<uint32_t> objs, float e0, float e1) {
+  float extent[3];
+  for (int axis = 0; axis < 3; axis++) {  // bvh.rs:27-35
+    float lo = kF32Max, hi = -kF32Max;
+    for (uint32_t id : objs) {
+      Box3 bb = bounding_box(id, e0, e1);
+      lo = fmin_rs(lo, fmin_rs(bb.mn[axis], bb.mx[axis]));
+      hi = fmax_rs(hi, fmax_rs(bb.mn[axis], bb.mx[axis]));
+    }
+    extent[axis] = hi - lo;
+    if (extent[axis] != extent[axis]) throw BuildError{-3, "Bvh::new: NaN extent (partial_cmp().unwrap())"};
+  }
+  int axis = 0;  // bvh.rs:38-47: descending sort of three, first maximum wins
+  if (extent[1] > extent[axis]) axis = 1;
+  if (extent[2] > extent[axis]) axis = 2;
+
+  std::vector<std::pair<float, uint32_t>> keyed;  // bvh.rs:51-57
+  keyed.reserve(objs.size());
+  for (uint32_t id : objs) {
+    Box3 bb = bounding_box(id, e0, e1);
+    float key = bb.mn[axis] + bb.mx[axis];
+    if (key != key) throw BuildError{-3, "Bvh::new: NaN centroid (partial_cmp().unwrap())"};
+    keyed.emplace_back(key, id);
+  }
+  std::stable_sort(keyed.begin(), keyed.end(),
+                   [](const std::pair<float, uint32_t>& p, const std::pair<float, uint32_t>& q) {
+                     return p.first < q.first;
+                   });
+  HostBvhNode node;
+  if (keyed.size() == 1) {  // bvh.rs:61-65
+    node.box = bounding_box(keyed[0].second, e0, e1);
+    node.leaf = keyed[0].second;
+  } else {  // bvh.rs:66-79
+    size_t half = keyed.size() / 2;
+    std::vector<uint32_t> l, r;
+    for (size_t i = 0; i < keyed.size(); i++) (i < half ? l : r).push_back(keyed[i].second);
+    node.right = build_bvh(std::move(r), e0, e1);
+    node.left = build_bvh(std::move(l), e0, e1);
+    node.box = merge(bvh_nodes[node.left].box, bvh_nodes[node.right].box);
+  }
+  bvh_nodes.push_back(node);
+  return (int32_t)bvh_nodes.size() - 1;
+}
+
+uint32_t SceneBuilder::add_bvh(const uint32_t* objs, size_t n, float e0, float e1) {
+  if (n == 0) throw BuildError{-2, "Can't create a BVH from zero objects."};  // bvh.rs:60
+  std::vector<uint32_t> v(objs, objs + n);
+  for (uint32_t id : v)
+    if (id >= objects.size()) throw BuildError{-1, "bvh: bad object handle"};
+  HostObject o;
+  o.kind = HostObject::BVH;
+  o.a = (uint32_t)build_bvh(std::move(v), e0, e1);
+  objects.push_back(o);
+  return (uint32_t)objects.size() - 1;
+}
+
+// ---- flattening ------------------------------------------------------------------------------------
+namespace {
+void push(FlatScene* s, float a, float b, float c, float d, uint32_t e, uint32_t f, uint32_t g, uint32_t h) {
+  s->lo.push_back(Packet{{fbits(a), fbits(b), fbits(c), fbits(d)}});
+  s->hi.push_back(Packet{{e, f, g, h}});
+}
+}  // namespace
+
+// Peel FlipNormals* [Translate] FlipNormals* Sphere, or FlipNormals* Rect, into one fused record.
+// (FlipNormals commutes exactly with Translate: one negates the normal, the other shifts p.)
+static bool fuse_primitive(const SceneBuilder& b, uint32_t id, FlatScene* out, bool emit_it) {
+  bool flip = false, have_t = false;
+  float off[3] = {0, 0, 0};
+  for (;;) {
+    const HostObject& o = b.objects[id];
+    if (o.kind == HostObject::FLIP) {
+      flip = !flip;
+      id = o.a;
+    } else if (o.kind == HostObject::TRANSLATE && !have_t) {
+      have_t = true;
+      off[0] = o.f[0], off[1] = o.f[1], off[2] = o.f[2];
+      id = o.a;
+    } else if (o.kind == HostObject::SPHERE) {
+      if (emit_it)
+        push(out, off[0], off[1], off[2], o.f[0], 0, 0, o.mat,
+             OP_SPHERE | (have_t ? F_TRANSLATE : 0u) | (flip ? F_FLIP : 0u));
+      return true;
+    } else if (o.kind == HostObject::RECT && !have_t) {
+      if (emit_it) {
+        push(out, o.f[0], o.f[1], o.f[2], o.f[3], fbits(o.f[4]), 0, o.mat,
+             OP_RECT | ((uint32_t)o.axis << F_AXIS_SHIFT) | (flip ? F_FLIP : 0u));
+        out->features |= FEAT_RECT;
+      }
+      return true;
+    } else {
+      return false;
+    }
+  }
+}
+
+void SceneBuilder::emit_bvh(int32_t node_id, int depth, FlatScene* out) const {
+  const HostBvhNode& n = bvh_nodes[node_id];
+  size_t at = out->lo.size();
+  push(out, n.box.mn[0], n.box.mn[1], n.box.mn[2], n.box.mx[0], fbits(n.box.mx[1]), fbits(n.box.mx[2]), 0, OP_BOX);
+  if (n.leaf != kNone) {
+    emit(n.leaf, true, false, depth, out);
+  } else {
+    emit_bvh(n.left, depth, out);
+    emit_bvh(n.right, depth, out);
+  }
+  out->hi[at].w[2] = (uint32_t)out->lo.size();  // skip pointer: first instruction after the subtree
+}
+
+void SceneBuilder::emit(uint32_t id, bool under_bvh, bool and_in_bvh, int depth, FlatScene* out) const {
+  const HostObject& o = objects[id];
+  if (fuse_primitive(*this, id, out, true)) return;
+  switch (o.kind) {
+    case HostObject::AND:
+      emit(o.a, under_bvh, under_bvh, depth, out);
+      emit(o.b, under_bvh, under_bvh, depth, out);
+      return;
+    case HostObject::BVH: {
+      size_t root = out->lo.size();
+      emit_bvh((int32_t)o.a, depth, out);
+      if (!under_bvh) out->hi[root].w[3] |= F_BVH_ROOT;
+      return;
+    }
+    case HostObject::MEDIUM: {
+      if (and_in_bvh)
+        throw BuildError{-5, "ConstantMedium below an And below a Bvh is not expressible in the flat program"};
+      if (!fuse_primitive(*this, o.a, out, false))
+        throw BuildError{-5, "ConstantMedium boundary must be a Sphere / Translate{Sphere} / Rect (optionally FlipNormals)"};
+      push(out, o.f[0], 0, 0, 0, 0, 0, o.mat, OP_MEDIUM | (under_bvh ? F_UNDER_BVH : 0u));
+      fuse_primitive(*this, o.a, out, true);
+      out->features |= FEAT_MEDIUM;
+      return;
+    }
+    default: break;
+  }
+  // generic wrapper: PUSH, subtree, POP
+  uint32_t kind;
+  switch (o.kind) {
+    case HostObject::TRANSLATE: kind = XF_TRANSLATE; break;
+    case HostObject::ROTATE_Y: kind = XF_ROTATE_Y; break;
+    case HostObject::SCALE: kind = XF_SCALE; break;
+    case HostObject::MOVE: kind = XF_MOVE; break;
+    case HostObject::FLIP: kind = XF_FLIP; break;
+    default: throw BuildError{-1, "flatten: unknown object kind"};
+  }
+  if (depth >= MAX_XFORM_DEPTH)
+    throw BuildError{-5, "transform wrappers nested deeper than the kernel's ray stack (4)"};
+  out->features |= FEAT_XFORM;
+  size_t at = out->lo.size();
+  push(out, o.f[0], o.f[1], o.f[2], 0, 0, 0, 0, OP_PUSH | (kind << F_KIND_SHIFT));
+  emit(o.a, under_bvh, and_in_bvh, depth + 1, out);
+  out->hi[at].w[2] = (uint32_t)out->lo.size();
+  push(out, o.f[0], o.f[1], o.f[2], 0, 0, 0, (uint32_t)at, OP_POP | (kind << F_KIND_SHIFT));
+}
+
+void SceneBuilder::flatten(const uint32_t* world, size_t n, FlatScene* out) const {
+  out->lo.clear(), out->hi.clear(), out->mat.clear(), out->tex.clear();
+  out->features = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (world[i] >= objects.size()) throw BuildError{-1, "scene: bad world object handle"};
+    emit(world[i], false, false, 0, out);
+  }
+  push(out, 0, 0, 0, 0, 0, 0, 0, OP_END);
+  for (const HostMaterial& m : materials) {
+    float c[3] = {m.albedo[0], m.albedo[1], m.albedo[2]};
+    uint32_t texkind = TEX_CONSTANT, tex = 0;
+    if (m.tex != kNone) {
+      const HostTexture& t = textures[m.tex];
+      texkind = t.kind;
+      tex = m.tex;
+      if (t.kind == TEX_CONSTANT) c[0] = t.rgb[0], c[1] = t.rgb[1], c[2] = t.rgb[2];
+      else out->features |= FEAT_TEXTURE;
+    }
+    out->mat.push_back(Packet{{fbits(c[0]), fbits(c[1]), fbits(c[2]), fbits(m.param)}});
+    out->mat.push_back(Packet{{tex, 0, 0, m.kind | (texkind << 8)}});
+  }
+  for (const HostTexture& t : textures) {
+    out->tex.push_back(Packet{{fbits(t.rgb[0]), fbits(t.rgb[1]), fbits(t.rgb[2]), fbits(t.scale)}});
+    out->tex.push_back(Packet{{t.t0, t.t1, 0, t.kind}});
+  }
+  out->perlin_vecs = perlin_vecs;
+  out->perlin_perm = perlin_perm;
+  out->has_perlin = has_perlin;
+}
+
+}  // namespace rtg

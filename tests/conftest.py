@@ -1,0 +1,53 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import __graft_entry__ as graft  # noqa: E402
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: exhaustive scans, excluded from the default CPU run")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return graft.load_package()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """TEST INFRASTRUCTURE: the CPU restatement (oracle/liboracle.so)."""
+    return graft.load_oracle()
+
+
+@pytest.fixture(scope="session")
+def gpu(pkg):
+    """The HIP product through its C ABI.  Fails loudly if the library is missing or no GPU."""
+    be = pkg.load()
+    n = be.device_count()
+    assert n >= 1, "no HIP device visible"
+    return be
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_bit_equal(a, b, what=""):
+    """Bit-exact float32 equality; NaNs compare equal to NaNs (x86 and gfx950 differ in NaN sign/payload)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    same = (bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))
+    if not same.all():
+        idx = np.argwhere(~same)
+        first = tuple(idx[0])
+        raise AssertionError("%s: %d of %d floats differ; first at %s: %r vs %r" % (
+            what, idx.shape[0], a.size, first, a[first], b[first]))

@@ -1,0 +1,53 @@
+"""Scene cases shared by the oracle tests, the GPU parity tests and the golden-fixture generator."""
+import numpy as np
+
+
+def _volume_in_bvh(pkg, b, nx, ny):
+    """volume_test's world under bvh::from_scene (the USE_BVH = true path, main.rs:340-345):
+    a ConstantMedium as a Bvh leaf exercises the hl.t < hr.t merge rule (bvh.rs:104-112)."""
+    world, cam, exp = pkg.scenes.volume_test(b, nx, ny)
+    return [b.bvh(world, exp)], cam, exp
+
+
+def _book2_bvh(pkg, b, nx, ny):
+    world, cam, exp = pkg.scenes.book_final_scene(b, nx, ny, pkg.small_rng.SmallRng(0xDEADBEEF))
+    return [b.bvh(world, exp)], cam, exp
+
+
+def _checker_scale(pkg, b, nx, ny):
+    """Surface not used by any live reference scene: checker texture (texture.rs:12) and Scale
+    (object.rs:296) -- SURVEY.md 8(f) item 4."""
+    S = pkg.scenes
+    world = S.cornell_box(b)
+    chk = b.lambertian(b.checker(b.constant(S.v(0.2, 0.3, 0.1)), b.constant(S.vfrom(0.9))))
+    world.append(b.translate(S.v(278.0, 120.0, 278.0), b.scale(S.v(1.0, 0.5, 1.5), b.sphere(120.0, chk))))
+    world.append(b.translate(S.v(150.0, 300.0, 200.0),
+                             b.flip_normals(b.flip_normals(b.sphere(60.0, b.metal(S.v(0.8, 0.85, 0.88), 0.3))))))
+    cam, exp = S._cornell_camera(b.be, nx, ny)
+    return world, cam, exp
+
+
+CASES = {
+    # name: (builder fn (pkg, b, nx, ny) -> (world, cam, exposure), nx, ny, ns)
+    "cornell": (lambda pkg, b, nx, ny: pkg.scenes.cornell_box_scene(b, nx, ny), 32, 32, 16),
+    "book1": (lambda pkg, b, nx, ny: pkg.scenes.random_scene(b, nx, ny), 48, 32, 8),
+    "book1_list": (lambda pkg, b, nx, ny: pkg.scenes.random_scene(b, nx, ny, use_bvh=False), 24, 16, 4),
+    "book2": (lambda pkg, b, nx, ny: pkg.scenes.book_final_scene(b, nx, ny, pkg.small_rng.SmallRng(0xDEADBEEF)),
+              32, 32, 8),
+    "book2_bvh": (_book2_bvh, 32, 32, 8),
+    "bench": (lambda pkg, b, nx, ny: pkg.scenes.bench_scene(b, nx, ny), 10, 10, 4),
+    "motion": (lambda pkg, b, nx, ny: pkg.scenes.motion_test(b, nx, ny), 32, 32, 8),
+    "volume": (lambda pkg, b, nx, ny: pkg.scenes.volume_test(b, nx, ny), 32, 32, 8),
+    "volume_bvh": (_volume_in_bvh, 32, 32, 8),
+    "simple_light": (lambda pkg, b, nx, ny: pkg.scenes.simple_light_scene(
+        b, nx, ny, pkg.small_rng.SmallRng(0xDEADBEEF), spheres=200), 24, 24, 4),
+    "checker_scale": (_checker_scale, 32, 32, 8),
+}
+
+
+def build_case(pkg, backend, name, nx=None, ny=None):
+    fn, dnx, dny, dns = CASES[name]
+    nx, ny = nx or dnx, ny or dny
+    b = backend.builder()
+    world, cam, _ = fn(pkg, b, nx, ny)
+    return b.scene(world), cam, nx, ny, dns
