@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s of the path-tracing hot path on MI355X (BASELINE.json metric).
+
+A "step" = one full par_cast of the workload into a framebuffer resident in HBM.
+  N = 1 : book-1 random-spheres, 1200x800, 50 spp (BASELINE.json configs[1]).
+  N > 1 : the same frame at 50*N spp, pixel tiles sharded over the N ranks (weak scaling: per-GPU
+          samples fixed), then ONE RCCL reduce(sum) of the float3 framebuffer to rank 0.
+Launch for N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(pkg, nx, ny, target_seconds=12.0, max_spp=50):
+    """TEST-INFRASTRUCTURE leg: time the CPU oracle (C++ restatement, row-parallel like lib.rs:326-330)
+    on all host cores, on a bounded sample of the same workload (same scene/seed, reduced spp)."""
+    ora = graft.load_oracle()
+    b = ora.builder()
+    world, cam, _ = pkg.scenes.random_scene(b, nx, ny)
+    scene = b.scene(world)
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    scene.par_cast(cam, nx, ny, 1, threads=cores)
+    t1 = time.perf_counter() - t0
+    spp = int(max(1, min(max_spp, target_seconds / max(t1, 1e-3))))
+    t0 = time.perf_counter()
+    scene.par_cast(cam, nx, ny, spp, threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": nx * ny * spp / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "book-1 %dx%d at %d spp (same scene and seed), oracle par_cast on %d threads, %.1f s"
+                      % (nx, ny, spp, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nx", type=int, default=1200)
+    ap.add_argument("--ny", type=int, default=800)
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel (default 50 * gpus)")
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xDEADBEEF)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    pkg = graft.load_package()
+    gpu = pkg.load()
+    nx, ny = args.nx, args.ny
+    spp = args.spp or 50 * world
+
+    b = gpu.builder()
+    objs, cam, _ = pkg.scenes.random_scene(b, nx, ny)
+    scene = b.scene(objs, device=local_rank)
+    info = scene.info()
+
+    fb = torch.zeros((ny, nx, 3), dtype=torch.float32, device=dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def step(flags=0):
+        p = pkg.make_params(nx, ny, spp, seed=args.seed, rank=rank, nranks=world, flags=flags)
+        st = scene.par_cast_device(cam, p, ctypes.c_void_p(fb.data_ptr()), stream, want_stats=True)
+        if world > 1:
+            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+        return st
+
+    # counting pass (untimed): the instrumented kernel gives N/P/H for the algorithmic byte model
+    fb.zero_()
+    cst = step(flags=pkg.capi.FLAG_COUNTERS)
+    px_rank = cst["samples"] // spp
+    algo_bytes = 32 * cst["aabb_tests"] + 32 * cst["prim_tests"] + 32 * cst["shaded_hits"] + 12 * px_rank
+
+    for _ in range(args.warmup):
+        fb.zero_()
+        step()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        if world > 1:
+            fb.zero_()
+        kernel_ms.append(step()["kernel_ms"])
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        total_samples = nx * ny * spp
+        avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+        achieved = algo_bytes / (avg_kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if world == 1 and os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("workload") == "book1_%dx%dx%d" % (nx, ny, spp):
+                    traffic = tj["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Msamples/s (pixels*spp/s), book-1 random-spheres %dx%d" % (nx, ny),
+            "value": total_samples / (elapsed / args.steps) / 1e6,
+            "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "book1_random_spheres_%dx%dx%dspp" % (nx, ny, spp),
+                "scene": "SmallRng(0xDEADBEEF) book-1 random spheres under bvh::from_scene + sky-dome emitter "
+                         "(SURVEY.md 8d), %d flat-program instructions, %d materials, %d B in HBM"
+                         % (info["instructions"], info["materials"], info["hbm_bytes"]),
+                "max_bounces": 50, "seed": hex(args.seed),
+                "sharding": "none" if world == 1 else
+                            "interleaved 16x16 pixel tiles (tile %% %d == rank), spp = 50*N; RCCL reduce(sum) of the "
+                            "float3 framebuffer to rank 0" % world,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "render_kernel", "kernel_ms_avg": avg_kernel_ms,
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "counters_per_launch": {k: cst[k] for k in ("aabb_tests", "prim_tests", "shaded_hits", "rays", "draws")},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(pkg, nx, ny)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
