@@ -23,6 +23,19 @@ import __graft_entry__ as graft  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def usable_cores():
+    """Threads this process may really run: affinity mask capped by the cgroup CPU quota
+    (the GPU box shows 256 hardware threads but its container is quota-limited)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(pkg, nx, ny, target_seconds=12.0, max_spp=50):
     """TEST-INFRASTRUCTURE leg: time the CPU oracle (C++ restatement, row-parallel like lib.rs:326-330)
     on all host cores, on a bounded sample of the same workload (same scene/seed, reduced spp)."""
@@ -30,7 +43,7 @@ def cpu_baseline(pkg, nx, ny, target_seconds=12.0, max_spp=50):
     b = ora.builder()
     world, cam, _ = pkg.scenes.random_scene(b, nx, ny)
     scene = b.scene(world)
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     t0 = time.perf_counter()
     scene.par_cast(cam, nx, ny, 1, threads=cores)
     t1 = time.perf_counter() - t0
@@ -128,6 +141,8 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if world == 1 and os.path.exists(tpath):
+            # measured separately (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command,
+            # tools/summarize_pmc.py); counters cannot be read from inside the process
             try:
                 tj = json.load(open(tpath))
                 if tj.get("workload") == "book1_%dx%dx%d" % (nx, ny, spp):
