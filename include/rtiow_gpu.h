@@ -164,6 +164,11 @@ int rtg_debug_samples(rtg_scene* s, const rtg_camera* camera, const rtg_params* 
  * 3 = sqrtf, 4 = 1/x, 5 = x/y with y = in2[i] (in2 may be NULL for unary ops). */
 int rtg_debug_math(int device, int op, size_t n, const float* in, const float* in2, float* out);
 
+/* Host-only: flatten `world` and copy the flat program out (8 words per instruction: the lo packet
+ * then the hi packet, see csrc/flat_scene.h).  Works without a GPU; used by the CPU-side tests. */
+int rtg_debug_flatten(rtg_builder* b, const rtg_id* world, size_t n, uint32_t* n_instructions,
+                      uint32_t* features, uint32_t* words_out, size_t capacity_instructions);
+
 #ifdef __cplusplus
 }
 #endif

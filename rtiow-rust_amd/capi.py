@@ -1,10 +1,9 @@
-"""ctypes binding of the C ABI declared in include/rtiow_gpu.h.
+"""ctypes binding of the C ABI declared in include/rtiow_gpu.h (librtiow_gpu.so, prefix ``rtg_``).
 
-The same binder drives the HIP product (`librtiow_gpu.so`, prefix ``rtg_``) and -- from tests and
-bench.py's cpu_baseline only -- the CPU oracle (`oracle/liboracle.so`, prefix ``rto_``), because the
-oracle exports the same entry points name for name.  Method names mirror the reference crate's
-constructors (object.rs / material.rs / texture.rs / camera.rs / lib.rs) so scene code reads like
-the reference's `src/main.rs`.
+Method names mirror the reference crate's constructors (object.rs / material.rs / texture.rs /
+camera.rs / lib.rs) so scene code reads like the reference's `src/main.rs`.  The symbol prefix is a
+parameter so that a test harness can drive another library exporting the same entry points with the
+same calls.
 """
 import ctypes as C
 import os
@@ -73,7 +72,7 @@ ABI_SYMBOLS = [
     "material_isotropic", "object_sphere", "object_rect", "object_flip_normals", "object_translate",
     "object_scale", "object_rotate_y", "object_and", "object_rect_prism", "object_linear_move",
     "object_constant_medium", "object_bvh", "camera_look", "scene_create", "scene_destroy",
-    "scene_info", "par_cast", "par_cast_device", "debug_hit_top", "debug_samples", "debug_math",
+    "scene_info", "par_cast", "par_cast_device", "debug_hit_top", "debug_samples", "debug_math", "debug_flatten",
 ]
 
 
@@ -87,8 +86,6 @@ class Backend:
         self.path = path
         self.prefix = prefix
         self.lib = C.CDLL(path)
-        self.is_oracle = prefix == "rto_"
-        L = self.lib
         f = self._fn
         f("last_error", C.c_char_p, [])
         f("version", C.c_char_p, [])
@@ -117,22 +114,20 @@ class Backend:
         f("camera_look", C.c_int, [c_f32p, c_f32p, c_f32p] + [C.c_float] * 6 + [C.POINTER(Camera)])
         f("scene_create", C.c_int, [C.c_void_p, c_u32p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)])
         f("scene_destroy", None, [C.c_void_p])
-        if self.is_oracle:
-            f("par_cast", C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), c_f32p,
-                                    C.POINTER(Stats), C.c_int])
-            f("cast", C.c_int, [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32,
-                                C.c_uint32, C.c_uint64, c_f32p])
-        else:
-            f("device_count", C.c_int, [C.POINTER(C.c_int)])
-            f("scene_info", C.c_int, [C.c_void_p, c_u32p, c_u32p, c_u32p, C.POINTER(C.c_uint64)])
-            f("par_cast", C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), c_f32p,
-                                    C.POINTER(Stats)])
-            f("par_cast_device", C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_void_p,
-                                           C.c_void_p, C.POINTER(Stats)])
+        self._declare_render()
         f("debug_hit_top", C.c_int, [C.c_void_p, C.c_size_t, c_f32p, C.c_uint64, C.c_float, c_f32p, c_u32p])
         f("debug_samples", C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_size_t,
                                      c_u32p, c_u32p, c_u32p, c_f32p, c_u32p])
         f("debug_math", C.c_int, [C.c_int, C.c_int, C.c_size_t, c_f32p, c_f32p, c_f32p])
+
+    def _declare_render(self):
+        f = self._fn
+        f("device_count", C.c_int, [C.POINTER(C.c_int)])
+        f("scene_info", C.c_int, [C.c_void_p, c_u32p, c_u32p, c_u32p, C.POINTER(C.c_uint64)])
+        f("par_cast", C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), c_f32p, C.POINTER(Stats)])
+        f("par_cast_device", C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_void_p,
+                                       C.c_void_p, C.POINTER(Stats)])
+        f("debug_flatten", C.c_int, [C.c_void_p, c_u32p, C.c_size_t, c_u32p, c_u32p, c_u32p, C.c_size_t])
 
     def _fn(self, name, restype, argtypes):
         fn = getattr(self.lib, self.prefix + name)
@@ -271,12 +266,22 @@ class Builder:
         arr = (C.c_uint32 * max(1, len(objs)))(*objs)
         return self.be.check_id(self.be._object_bvh(self.h, arr, len(objs), exposure[0], exposure[1]))
 
+    def flatten(self, world):
+        """Host-only (product library): the flat program as uint32 [n, 8] plus the feature mask."""
+        arr = (C.c_uint32 * max(1, len(world)))(*world)
+        n, feat = C.c_uint32(), C.c_uint32()
+        self.be.check(self.be._debug_flatten(self.h, arr, len(world), C.byref(n), C.byref(feat), None, 0))
+        words = np.zeros((n.value, 8), dtype=np.uint32)
+        self.be.check(self.be._debug_flatten(self.h, arr, len(world), C.byref(n), C.byref(feat),
+                                             words.ctypes.data_as(c_u32p), n.value))
+        return words, feat.value
+
     def scene(self, world, device=0):
         """Flatten `world` (the `[Box<dyn Object>]` of lib.rs:33) once into device memory."""
         arr = (C.c_uint32 * max(1, len(world)))(*world)
         h = C.c_void_p()
         self.be.check(self.be._scene_create(self.h, arr, len(world), device, C.byref(h)))
-        return Scene(self.be, h, self)
+        return self.be.scene_class(self.be, h, self)
 
 
 class Scene:
@@ -301,6 +306,9 @@ class Scene:
         self.be.check(self.be._scene_info(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return {"instructions": a.value, "materials": b.value, "textures": c.value, "hbm_bytes": d.value}
 
+    def _par_cast_args(self, args, threads):
+        return args
+
     def par_cast(self, camera, nx, ny, ns, seed=0xDEADBEEF, stats=False, out=None, threads=0, **kw):
         """par_cast, lib.rs:363.  Returns float32 [ny, nx, 3], row 0 = top, linear radiance."""
         p = make_params(nx, ny, ns, seed=seed, flags=FLAG_COUNTERS if stats else 0, **kw)
@@ -308,9 +316,8 @@ class Scene:
             out = np.zeros((ny, nx, 3), dtype=np.float32)
         st = Stats()
         st.struct_size = C.sizeof(Stats)
-        args = [self.h, C.byref(camera), C.byref(p), out.ctypes.data_as(c_f32p), C.byref(st)]
-        if self.be.is_oracle:
-            args.append(threads)
+        args = self._par_cast_args([self.h, C.byref(camera), C.byref(p), out.ctypes.data_as(c_f32p), C.byref(st)],
+                                   threads)
         self.be.check(self.be._par_cast(*args))
         return (out, st.as_dict()) if stats else out
 
@@ -320,13 +327,6 @@ class Scene:
         self.be.check(self.be._par_cast_device(self.h, C.byref(camera), C.byref(params), d_out_ptr, stream,
                                                C.byref(st) if want_stats else None))
         return st.as_dict() if want_stats else None
-
-    def cast(self, camera, nx, ny, ns, small_rng_seed=0xDEADBEEF, max_bounces=50):
-        """cast, lib.rs:378 (oracle only): sequential, one SmallRng stream."""
-        out = np.zeros((ny, nx, 3), dtype=np.float32)
-        self.be.check(self.be._cast(self.h, C.byref(camera), nx, ny, ns, max_bounces, small_rng_seed,
-                                    out.ctypes.data_as(c_f32p)))
-        return out
 
     def debug_hit_top(self, rays, seed=1, t_near=0.001):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 7)
@@ -348,3 +348,6 @@ class Scene:
                                              samples.ctypes.data_as(c_u32p), rgb.ctypes.data_as(c_f32p),
                                              info.ctypes.data_as(c_u32p)))
         return rgb, info
+
+
+Backend.scene_class = Scene

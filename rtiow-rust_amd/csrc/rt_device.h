@@ -40,7 +40,7 @@ RT_DEV V3 reflect(V3 v, V3 n) { return vsub(v, smul(2.f * vdot(v, n), n)); }
 
 constexpr float F32_MAX = 3.402823466e+38f;
 
-// ---- libm restatements (same algorithms as oracle/rto_core.hpp; parity tests compare them) ------
+// ---- libm restatements (the CPU checker runs the same algorithms; parity tests compare them) ------
 struct LogfEntry {
   double invc, logc;
 };

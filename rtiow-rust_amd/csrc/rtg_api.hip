@@ -619,6 +619,27 @@ int rtg_debug_samples(rtg_scene* s, const rtg_camera* camera, const rtg_params* 
   return RTG_OK;
 }
 
+int rtg_debug_flatten(rtg_builder* b, const rtg_id* world, size_t n, uint32_t* n_instructions, uint32_t* features,
+                      uint32_t* words_out, size_t capacity) {
+  if (!b || (!world && n)) return fail(RTG_ERR_INVALID, "null argument");
+  FlatScene fs;
+  try {
+    b->sb.flatten(world, n, &fs);
+  } catch (const BuildError& e) {
+    return fail(e.code, e.msg);
+  }
+  if (n_instructions) *n_instructions = (uint32_t)fs.lo.size();
+  if (features) *features = fs.features;
+  if (words_out) {
+    size_t m = fs.lo.size() < capacity ? fs.lo.size() : capacity;
+    for (size_t i = 0; i < m; i++) {
+      std::memcpy(words_out + 8 * i, fs.lo[i].w, 16);
+      std::memcpy(words_out + 8 * i + 4, fs.hi[i].w, 16);
+    }
+  }
+  return RTG_OK;
+}
+
 int rtg_debug_math(int device, int op, size_t n, const float* in, const float* in2, float* out) {
   if (!in || !out || op < 0 || op > 5 || (op == 5 && !in2)) return fail(RTG_ERR_INVALID, "bad argument");
   int ndev = 0;

@@ -1,0 +1,44 @@
+"""The N>1 path on CPU: world_size-2 gloo.  Each rank renders its pixel-tile shard into a zero-filled
+full frame, ONE reduce(sum) assembles it on rank 0 -- the same rtiow_rust_amd.parallel code bench.py's
+multi-GPU leg uses over RCCL.  (The shard renderer here is the oracle: there is no GPU in this box.)"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import __graft_entry__ as graft
+from scene_cases import build_case
+pkg = graft.load_package(); ora = graft.load_oracle()
+from rtiow_rust_amd import parallel
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+scene, cam, nx, ny, ns = build_case(pkg, ora, "book1", 64, 48)
+def render_shard(fb, rank, world):
+    part = scene.par_cast(cam, nx, ny, ns, rank=rank, nranks=world, threads=2)
+    fb.copy_(torch.from_numpy(part))
+frame = parallel.render_sharded(render_shard, nx, ny, rank, world, torch.device("cpu"))
+if rank == 0:
+    np.save(sys.argv[1], frame.numpy())
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_reduce_equals_single_frame(tmp_path, pkg, oracle):
+    from conftest import assert_bit_equal
+    from scene_cases import build_case
+    out = str(tmp_path / "frame.npy")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), out], env=dict(env, RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    scene, cam, nx, ny, ns = build_case(pkg, oracle, "book1", 64, 48)
+    assert_bit_equal(np.load(out), scene.par_cast(cam, nx, ny, ns), "2-rank sharded frame")

@@ -21,3 +21,179 @@ def test_framebuffer_bit_exact(pkg, gpu, oracle, name):
         assert st_g[k] == st_o[k], (name, k, st_g[k], st_o[k])
     # the non-instrumented kernel variant is the one that is timed: must give the same image
     assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns), img_o, name + " (timed variant)")
+
+
+# ---- golden fixtures (committed, minted by tools/gen_golden.py from the oracle) ----------------------
+import os  # noqa: E402
+
+from probe_rays import probe_rays  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_gpu_matches_golden_framebuffer(pkg, gpu, name):
+    gold = np.load(os.path.join(GOLD, "framebuffers.npz"))[name]
+    sg, cam, nx, ny, ns = build_case(pkg, gpu, name)
+    assert_bit_equal(sg.par_cast(cam, nx, ny, ns), gold, name)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_per_sample_traces(pkg, gpu, name):
+    """64 fixed (pixel, sample) keys per scene: colour, bounce count, RNG draws consumed, Aabb tests,
+    primitive tests -- all must equal the oracle's (same traversal order, same draw order)."""
+    g = np.load(os.path.join(GOLD, "samples.npz"))
+    xs, ys, ss = g[name + ".keys"]
+    sg, cam, nx, ny, ns = build_case(pkg, gpu, name)
+    rgb, info = sg.debug_samples(cam, nx, ny, ns, xs, ys, ss)
+    assert np.array_equal(info, g[name + ".info"]), name
+    assert_bit_equal(rgb, g[name + ".rgb"], name)
+
+
+@pytest.mark.parametrize("name", ["cornell", "book1", "book2", "volume_bvh", "checker_scale", "motion"])
+def test_hit_top_probes(pkg, gpu, oracle, name):
+    """World::hit_top on random + edge-case rays (zero direction components, NaN t, in-plane rays)."""
+    g = np.load(os.path.join(GOLD, "hit_top.npz"))
+    rays = g[name + ".rays"]
+    assert np.array_equal(rays, probe_rays(name))
+    sg, _, _, _, _ = build_case(pkg, gpu, name)
+    out, mat = sg.debug_hit_top(rays, seed=5)
+    assert np.array_equal(mat, g[name + ".mat"]), name
+    assert_bit_equal(out, g[name + ".out"], name)
+    # and live against the oracle on a different seed / ray set
+    so, _, _, _, _ = build_case(pkg, oracle, name)
+    rays2 = probe_rays(name, n_random=512, seed=99)
+    og, mg = sg.debug_hit_top(rays2, seed=77)
+    oo, mo = so.debug_hit_top(rays2, seed=77)
+    assert np.array_equal(mg, mo)
+    assert_bit_equal(og, oo, name + " live")
+
+
+# ---- scalar building blocks --------------------------------------------------------------------------
+def test_logf_full_rng_domain(gpu, oracle):
+    """rt_logf on EVERY value rng.gen::<f32>() can produce (k * 2^-24, k < 2^24): GPU == CPU bitwise."""
+    x = (np.arange(1 << 24, dtype=np.float64) / (1 << 24)).astype(np.float32)
+    assert_bit_equal(gpu.debug_math(0, x), oracle.debug_math(0, x), "rt_logf")
+
+
+def test_libm_restatements_and_ieee_ops(gpu, oracle):
+    rs = np.random.RandomState(3)
+    bits32 = rs.randint(0, 2 ** 32, size=1 << 20, dtype=np.uint64).astype(np.uint32)
+    anyf = bits32.view(np.float32)                    # every class: normals, denormals, inf, nan
+    unit = rs.uniform(-0.5, 1.0, 1 << 20).astype(np.float32)
+    wide = (rs.standard_normal(1 << 20) * 3000).astype(np.float32)
+    assert_bit_equal(gpu.debug_math(0, anyf), oracle.debug_math(0, anyf), "rt_logf any")
+    assert_bit_equal(gpu.debug_math(1, unit), oracle.debug_math(1, unit), "rt_pow5f")
+    assert_bit_equal(gpu.debug_math(1, anyf), oracle.debug_math(1, anyf), "rt_pow5f any")
+    assert_bit_equal(gpu.debug_math(2, wide), oracle.debug_math(2, wide), "rt_sinf")
+    assert_bit_equal(gpu.debug_math(2, anyf), oracle.debug_math(2, anyf), "rt_sinf any")
+    # correctly rounded sqrt / reciprocal / divide incl. denormals: the parity of everything else rests on these
+    assert_bit_equal(gpu.debug_math(3, anyf), oracle.debug_math(3, anyf), "sqrt")
+    assert_bit_equal(gpu.debug_math(4, anyf), oracle.debug_math(4, anyf), "1/x")
+    other = np.roll(anyf, 7)
+    assert_bit_equal(gpu.debug_math(5, anyf, other), oracle.debug_math(5, anyf, other), "x/y")
+    den = (rs.randint(1, 1 << 23, 1 << 16).astype(np.uint32)).view(np.float32)   # denormal operands
+    assert_bit_equal(gpu.debug_math(5, den, np.roll(den, 1)), oracle.debug_math(5, den, np.roll(den, 1)), "den/den")
+    assert_bit_equal(gpu.debug_math(3, den), oracle.debug_math(3, den), "sqrt(den)")
+
+
+# ---- sharding (multi-GPU path emulated on one device) --------------------------------------------------
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+def test_tile_shards_sum_to_full_frame(pkg, gpu, nranks):
+    sg, cam, nx, ny, ns = build_case(pkg, gpu, "book1", 112, 80)
+    full = sg.par_cast(cam, nx, ny, ns)
+    acc = np.zeros_like(full)
+    for r in range(nranks):
+        part = sg.par_cast(cam, nx, ny, ns, rank=r, nranks=nranks)
+        acc = acc + part
+    assert_bit_equal(acc, full, "%d shards" % nranks)
+
+
+def test_other_ranks_pixels_are_left_untouched(pkg, gpu):
+    sg, cam, nx, ny, ns = build_case(pkg, gpu, "cornell", 64, 64)
+    canvas = np.full((ny, nx, 3), 7.0, dtype=np.float32)
+    out = sg.par_cast(cam, nx, ny, 2, rank=1, nranks=4, tile_w=32, tile_h=16, out=canvas)
+    tiles_x = 2
+    for row in range(ny):
+        for x in range(0, nx, 16):
+            tile = (row // 16) * tiles_x + x // 32
+            if tile % 4 != 1:
+                assert (out[row, x:x + 16] == 7.0).all()
+
+
+# ---- error behaviour -------------------------------------------------------------------------------------
+def test_gen_range_assertion(pkg, gpu):
+    """camera.rs:55: gen_range(lo, hi) asserts lo < hi -> RTG_ERR_RANGE instead of a panic."""
+    b = gpu.builder()
+    world, cam, _ = pkg.scenes.cornell_box_scene(b, 16, 16)
+    cam.exposure_start, cam.exposure_end = 1.0, 1.0
+    with pytest.raises(pkg.RtError) as e:
+        b.scene(world).par_cast(cam, 16, 16, 1)
+    assert e.value.code == -4
+
+
+def test_ragged_image_sizes(pkg, gpu, oracle):
+    """Sizes that are not multiples of the 16x16 block / 8x8 wave tile, and 1-pixel images."""
+    for (nx, ny) in [(1, 1), (17, 9), (33, 47), (15, 64)]:
+        sg, cam_g, _, _, _ = build_case(pkg, gpu, "cornell", nx, ny)
+        so, cam_o, _, _, _ = build_case(pkg, oracle, "cornell", nx, ny)
+        assert_bit_equal(sg.par_cast(cam_g, nx, ny, 3), so.par_cast(cam_o, nx, ny, 3), "%dx%d" % (nx, ny))
+
+
+def test_bounce_cap_and_near_are_parameters(pkg, gpu, oracle):
+    for mb, near in [(0, 0.001), (3, 0.001), (50, 0.1)]:
+        sg, cam_g, nx, ny, _ = build_case(pkg, gpu, "book1", 40, 24)
+        so, cam_o, _, _, _ = build_case(pkg, oracle, "book1", 40, 24)
+        a = sg.par_cast(cam_g, nx, ny, 4, max_bounces=mb, t_near=near)
+        b_ = so.par_cast(cam_o, nx, ny, 4, max_bounces=mb, t_near=near)
+        assert_bit_equal(a, b_, "max_bounces=%d" % mb)
+
+
+# ---- BASELINE.json full sizes: size-independent properties + oracle bands ---------------------------------
+def _band(scene, cam, nx, ny, ns, band, nbands, **kw):
+    """Render only the `band`-th group of 16 rows (tile_w = nx, tile_h = 16, rank = band)."""
+    return scene.par_cast(cam, nx, ny, ns, tile_w=((nx + 15) // 16) * 16, tile_h=16, rank=band, nranks=nbands, **kw)
+
+
+def test_config_c2_book1_1200x800x50(pkg, gpu, oracle):
+    """configs[1]: book-1 1200x800x50 spp.  Determinism, shard-sum == frame, counters, and three 16-row
+    bands checked bit-for-bit against the oracle at full resolution and full spp."""
+    nx, ny, ns = 1200, 800, 50
+    sg, cam_g, _, _, _ = build_case(pkg, gpu, "book1", nx, ny)
+    so, cam_o, _, _, _ = build_case(pkg, oracle, "book1", nx, ny)
+    full, st = sg.par_cast(cam_g, nx, ny, ns, stats=True)
+    assert st["samples"] == nx * ny * ns and st["rays"] == st["shaded_hits"]  # sky dome: every ray hits
+    again = sg.par_cast(cam_g, nx, ny, ns)
+    assert_bit_equal(again, full, "run-to-run determinism")
+    acc = np.zeros_like(full)
+    for r in range(8):
+        acc += sg.par_cast(cam_g, nx, ny, ns, rank=r, nranks=8)
+    assert_bit_equal(acc, full, "8 shards")
+    assert np.isfinite(full).all() and 0.2 < full.mean() < 1.0
+    for band in (0, 24, 49):
+        ref = _band(so, cam_o, nx, ny, ns, band, 50)
+        rows = slice(band * 16, band * 16 + 16)
+        assert_bit_equal(full[rows], ref[rows], "band %d" % band)
+
+
+def test_config_c1_cornell_300x300x100(pkg, gpu, oracle):
+    """configs[0]: Cornell box + prisms 300x300x100 (list world), whole frame against the oracle."""
+    nx, ny, ns = 300, 300, 100
+    sg, cam_g, _, _, _ = build_case(pkg, gpu, "cornell", nx, ny)
+    so, cam_o, _, _, _ = build_case(pkg, oracle, "cornell", nx, ny)
+    assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns), so.par_cast(cam_o, nx, ny, ns), "cornell 300x300x100")
+
+
+@pytest.mark.parametrize("name", ["book2", "book2_bvh"])
+def test_config_c4_book2_800x800(pkg, gpu, oracle, name):
+    """configs[3]: book-2 final scene 800x800 (USE_BVH false and true).  Full resolution, reduced spp
+    for the oracle bands (the per-pixel fold is order-exact, so a prefix of the samples is a valid case)."""
+    nx, ny, ns = 800, 800, 16
+    sg, cam_g, _, _, _ = build_case(pkg, gpu, name, nx, ny)
+    so, cam_o, _, _, _ = build_case(pkg, oracle, name, nx, ny)
+    full = sg.par_cast(cam_g, nx, ny, ns)
+    assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns), full, "determinism")
+    for band in (5, 30, 44):
+        ref = _band(so, cam_o, nx, ny, ns, band, 50)
+        rows = slice(band * 16, band * 16 + 16)
+        assert_bit_equal(full[rows], ref[rows], "%s band %d" % (name, band))
