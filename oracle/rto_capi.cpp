@@ -320,7 +320,7 @@ static Vec3 one_sample(const World& world, const Camera& cam, const rto_params& 
   float u = ((float)x + rng.gen_f32()) / (float)p.nx;
   float v = ((float)y + rng.gen_f32()) / (float)p.ny;
   Ray r = cam.get_ray(u, v, rng);
-  return color(world, r, rng, counters, (int)p.max_bounces, bounces);
+  return color(world, r, rng, counters, (int)p.max_bounces, bounces, p.t_near);
 }
 
 static Vec3 one_pixel(const World& world, const Camera& cam, const rto_params& p, uint32_t x,
@@ -413,7 +413,7 @@ int rto_cast(rto_scene* s, const rto_camera* camera, uint32_t nx, uint32_t ny, u
 }
 
 // ---- probes ---------------------------------------------------------------------------------
-int rto_debug_hit_top(rto_scene* s, size_t n, const float* rays, uint64_t seed, float /*t_near*/,
+int rto_debug_hit_top(rto_scene* s, size_t n, const float* rays, uint64_t seed, float t_near,
                       float* out, uint32_t* out_material) {
   for (size_t i = 0; i < n; i++) {
     Ray r;
@@ -422,7 +422,7 @@ int rto_debug_hit_top(rto_scene* s, size_t n, const float* rays, uint64_t seed, 
     r.time = rays[7 * i + 6];
     SampleRng rng(seed, (uint32_t)i, 0);
     HitRecord h;
-    bool hit = s->world.hit_top(r, rng, nullptr, &h);
+    bool hit = s->world.hit_top(r, rng, nullptr, &h, t_near);
     float* o = out + 8 * i;
     o[0] = hit ? 1.f : 0.f;
     o[1] = hit ? h.t : 0.f;

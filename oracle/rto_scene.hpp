@@ -548,8 +548,8 @@ struct World {
   // impl World for Bvh (lib.rs:51-55) is a one-element list holding a Bvh: identical arithmetic
   // (obj.hit(ray, 0.001..f32::MAX)).
 
-  bool hit_top(const Ray& ray, Rng& rng, Counters* counters, HitRecord* rec) const {
-    const float NEAR = 0.001f;
+  // NEAR is the literal 0.001 of lib.rs:35,53; a parameter here because the C ABI exposes it.
+  bool hit_top(const Ray& ray, Rng& rng, Counters* counters, HitRecord* rec, float NEAR = 0.001f) const {
     if (counters) counters->rays++;
     float nearest = F32_MAX;
     bool any = false;
@@ -568,12 +568,12 @@ struct World {
 
 // lib.rs:60-101.  `max_bounces` is the literal 50 of lib.rs:93.
 inline Vec3 color(const World& world, Ray ray, Rng& rng, Counters* counters, int max_bounces,
-                  int* bounces_out) {
+                  int* bounces_out, float t_near = 0.001f) {
   Vec3 accum;
   Vec3 strength = Vec3::from(1.f);
   int bounces = 0;
   HitRecord hit;
-  while (world.hit_top(ray, rng, counters, &hit)) {
+  while (world.hit_top(ray, rng, counters, &hit, t_near)) {
     if (counters) counters->shaded_hits++;
     accum = accum + strength * hit.material->emitted(hit.p);
     Ray new_ray;
