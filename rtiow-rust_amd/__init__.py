@@ -15,7 +15,7 @@ There is NO CPU fallback: load() raises if the HIP library is missing.
 """
 import os
 
-from . import capi, scenes, small_rng  # noqa: F401  (parallel imports torch: import it explicitly)
+from . import capi, ppm, scenes, small_rng  # noqa: F401  (parallel imports torch: import it explicitly)
 from .capi import Backend, Camera, Params, Stats, RtError, make_params  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

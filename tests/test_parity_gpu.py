@@ -197,3 +197,16 @@ def test_config_c4_book2_800x800(pkg, gpu, oracle, name):
         ref = _band(so, cam_o, nx, ny, ns, band, 50)
         rows = slice(band * 16, band * 16 + 16)
         assert_bit_equal(full[rows], ref[rows], "%s band %d" % (name, band))
+
+
+def test_cxx_crate_mirror_example(pkg, gpu, tmp_path):
+    """host/examples/main.cpp = the reference's src/main.rs transliterated against host/rtiow.hpp.
+    Its PPM (print_ppm, lib.rs:344-361) must equal the one made from the ctypes path's framebuffer."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(GOLD), "..", "rtiow-rust_amd", "host", "examples", "rtiow_main")
+    exe = os.path.abspath(exe)
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    for which, case in (("cornell", "cornell"), ("motion", "motion"), ("volume", "volume")):
+        out = subprocess.run([exe, which, "40", "24", "6"], check=True, capture_output=True, text=True).stdout
+        sg, cam, nx, ny, _ = build_case(pkg, gpu, case, 40, 24)
+        assert out == pkg.ppm.format_ppm(sg.par_cast(cam, nx, ny, 6)), which
