@@ -421,6 +421,7 @@ int rto_debug_hit_top(rto_scene* s, size_t n, const float* rays, uint64_t seed, 
     r.direction = v3(rays + 7 * i + 3);
     r.time = rays[7 * i + 6];
     SampleRng rng(seed, (uint32_t)i, 0);
+    rng.set_event(1);
     HitRecord h;
     bool hit = s->world.hit_top(r, rng, nullptr, &h, t_near);
     float* o = out + 8 * i;
@@ -528,8 +529,9 @@ void rto_debug_small_rng_f32(uint64_t seed, size_t n, float* out) {
   SmallRng r(seed);
   for (size_t i = 0; i < n; i++) out[i] = r.gen_f32();
 }
-void rto_debug_sample_rng_u32(uint64_t seed, uint32_t pixel, uint32_t sample, size_t n, uint32_t* out) {
+void rto_debug_sample_rng_u32(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t event, size_t n, uint32_t* out) {
   SampleRng r(seed, pixel, sample);
+  r.set_event(event);
   for (size_t i = 0; i < n; i++) out[i] = r.next_u32();
 }
 int rto_debug_aabb_hit(const float mn[3], const float mx[3], const float o[3], const float d[3],

@@ -237,6 +237,9 @@ struct Rng {
   Counters* counters = nullptr;
   virtual ~Rng() = default;
   virtual uint32_t next_u32_impl() = 0;
+  // Counter-stream hook (see SampleRng): a new path event starts.  A sequential generator such as
+  // SmallRng -- the reference's own `impl Rng` -- has no such notion and ignores it.
+  virtual void set_event(uint32_t) {}
   uint32_t next_u32() {
     if (counters) counters->draws++;
     return next_u32_impl();
@@ -291,8 +294,12 @@ struct SmallRng final : Rng {
 };
 
 // The determinism contract of this build: one counter-based stream per
-// (seed, pixel, sample).  Philox4x32-10 (Salmon et al., SC'11; Random123), key = seed lo/hi,
-// counter = (block, sample, pixel, 0); a block yields 4 draws, consumed in order x,y,z,w.
+// (seed, pixel, sample, event).  Philox4x32-10 (Salmon et al., SC'11; Random123), key = seed lo/hi,
+// counter = (block, sample, pixel, event); a block yields 4 draws, consumed in order x,y,z,w.
+// event 0 = the camera ray of the sample (u, v, lens disc, shutter time; lib.rs:368-370);
+// event k >= 1 = the k-th hit_top() of the path plus the scatter that follows it (lib.rs:73-84).
+// Starting every event on a fresh block keeps a GPU wave's lanes in lock-step through the
+// rejection loops (no lane-divergent block generation) and makes a path's RNG state just (k).
 struct Philox4x32 {
   static void block(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                     uint32_t out[4]) {
@@ -312,13 +319,14 @@ struct Philox4x32 {
 };
 
 struct SampleRng final : Rng {
-  uint32_t k0, k1, sample, pixel, blk = 0, idx = 4;
+  uint32_t k0, k1, sample, pixel, event = 0, blk = 0, idx = 4;
   uint32_t buf[4];
   SampleRng(uint64_t seed, uint32_t pixel_, uint32_t sample_)
       : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)), sample(sample_), pixel(pixel_) {}
+  void set_event(uint32_t e) override { event = e, blk = 0, idx = 4; }
   uint32_t next_u32_impl() override {
     if (idx == 4) {
-      Philox4x32::block(k0, k1, blk, sample, pixel, 0u, buf);
+      Philox4x32::block(k0, k1, blk, sample, pixel, event, buf);
       blk++;
       idx = 0;
     }

@@ -573,6 +573,7 @@ inline Vec3 color(const World& world, Ray ray, Rng& rng, Counters* counters, int
   Vec3 strength = Vec3::from(1.f);
   int bounces = 0;
   HitRecord hit;
+  rng.set_event(1);  // determinism contract: event k = k-th hit_top + its scatter (rto_core.hpp)
   while (world.hit_top(ray, rng, counters, &hit, t_near)) {
     if (counters) counters->shaded_hits++;
     accum = accum + strength * hit.material->emitted(hit.p);
@@ -590,6 +591,7 @@ inline Vec3 color(const World& world, Ray ray, Rng& rng, Counters* counters, int
       return accum;
     }
     bounces += 1;
+    rng.set_event((uint32_t)bounces + 1);
   }
   if (bounces_out) *bounces_out = bounces;
   return Vec3();

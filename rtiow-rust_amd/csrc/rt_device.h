@@ -116,10 +116,12 @@ RT_DEV float rt_sinf(float x) {
 }
 
 // ---- counter RNG ---------------------------------------------------------------------------------
-// Determinism contract: one Philox4x32-10 stream per (seed, pixel, sample); key = seed,
-// counter = (block, sample, pixel, 0); each block hands out its 4 words in order.
+// Determinism contract: one Philox4x32-10 stream per (seed, pixel, sample, event); key =
+// seed, counter = (block, sample, pixel, event); each block hands out its 4 words in order.  event 0 =
+// camera ray, event k = k-th hit_top + scatter: every event starts on a fresh block, so the lanes of a
+// wave walk the rejection loops in lock-step (block generation is never lane-divergent).
 struct SampleRng {
-  uint32_t k0, k1, sample, pixel, blk;
+  uint32_t k0, k1, sample, pixel, event, blk;
   uint32_t b0, b1, b2, b3;  // unread words of the current block, b0 next
   uint32_t left;            // words left in b0..b3
   uint32_t draws;
@@ -129,17 +131,29 @@ struct SampleRng {
     k1 = (uint32_t)(seed >> 32);
     pixel = pixel_;
     sample = sample_;
+    event = 0;
     blk = 0;
     left = 0;
     draws = 0;
   }
+  RT_DEV void set_event(uint32_t e) {
+    event = e;
+    blk = 0;
+    left = 0;
+  }
   RT_DEV void refill() {
-    uint32_t c0 = blk, c1 = sample, c2 = pixel, c3 = 0u;
+    uint32_t c0 = blk, c1 = sample, c2 = pixel, c3 = event;
     uint32_t key0 = k0, key1 = k1;
+#ifndef RT_PHILOX_ROUNDS
+#define RT_PHILOX_ROUNDS 10
+#endif
 #pragma unroll
-    for (int round = 0; round < 10; round++) {
-      uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-      uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    for (int round = 0; round < RT_PHILOX_ROUNDS; round++) {
+      // one 32x32->64 multiply each (v_mad_u64_u32) instead of separate mul_hi + mul_lo
+      const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0;
+      const uint64_t p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
+      uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+      uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
       uint32_t n0 = hi1 ^ c1 ^ key0;
       uint32_t n2 = hi0 ^ c3 ^ key1;
       c0 = n0;

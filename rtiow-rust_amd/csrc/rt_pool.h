@@ -1,0 +1,420 @@
+// rt_pool.h -- "ray pool" kernel for lean scenes (spheres under Bvhs, constant textures): the tuned
+// path for the book-1 north-star workload.  Same arithmetic as rt_trace.h; the SCHEDULE is built for
+// CDNA4's 64-wide waves and 160 KB LDS:
+//
+//  * every wave owns a private pool of POOL = 128 path slots in LDS (2 per lane).  A slot holds a whole
+//    path state (ray, best hit, strength, accum, bounce/sample counters, pixel, running pixel sum).
+//  * the wave's 64 lanes only TRAVERSE: a lane holds (o, d, 1/d, best, pc, current record) of one
+//    slot's ray in registers and walks the flat program (staged in LDS).  When its ray reaches END the
+//    lane writes (best, best_pc) back to the slot, pushes the slot on the wave's S-list and refills from
+//    the T-list -- lanes do not wait for each other's paths (wave-ballot compaction of the active-ray
+//    stream: ballot + mbcnt prefix ranks, no atomics because the lists are wave-private).
+//  * when 64 slots wait on the S-list the wave runs ONE full-width SHADE pass over them (hit record,
+//    Material::scatter, next sample's camera ray, next pixel from the global work counter), writes the
+//    new rays into the slots and pushes them on the T-list.  Shading therefore always runs 64 lanes
+//    wide instead of "whoever happened to finish".
+//  * lanes that reach a SPHERE record park until enough of them wait, so the sqrt/divide sequence
+//    never runs for a handful of lanes; box steps run in a tight loop between schedule decisions.
+//  * workgroups are persistent (grid = CUs x resident workgroups); pixels come from one global
+//    counter with a wave-aggregated atomicAdd.
+//
+// Scheduling never changes results: every (pixel, sample, event) has its own RNG stream and a pixel's
+// samples are folded in order inside its slot.
+#pragma once
+#include "rt_persistent.h"
+
+namespace rtg {
+
+constexpr uint32_t POOL = 128;           // path slots per wave
+constexpr uint32_t POOL_FIELDS = 20;     // dwords per slot (SoA: field f of slot j at [f * POOL + j])
+constexpr uint32_t SLOT_NEED_PIXEL = 0xfffffffeu;  // best_pc marker: slot holds no ray yet
+
+enum PoolField : uint32_t {
+  PF_O = 0, PF_D = 3, PF_BEST = 6, PF_BEST_PC = 7, PF_STRENGTH = 8, PF_ACCUM = 11, PF_BOUNCES = 14, PF_SAMPLE = 15,
+  PF_XY = 16, PF_COL = 17,
+};
+
+// Sample-chunk mode.  One lane per pixel cannot fill the chip when a rank owns few pixels (8-GPU
+// shards, small images).  A work item is then (pixel, chunk of `chunk` consecutive samples); every
+// sample colour goes to an HBM scratch laid out [sample][pixel-work-index] and fold_samples_kernel
+// adds them per pixel IN SAMPLE ORDER afterwards -- the same left fold as lib.rs:365-374, bit for bit.
+struct ChunkMode {
+  float* scratch;      // null = off: a slot folds its pixel's samples itself
+  uint32_t chunk;      // samples per work item
+  uint32_t n_chunks;   // work items per pixel
+  uint32_t pix_work;   // pixel work items of this rank (tiles x tile area, incl. out-of-image padding)
+};
+
+// inverse of work_to_pixel
+RT_DEV uint32_t pixel_to_work(const DevParams& P, uint32_t x, uint32_t row) {
+  const uint32_t tiles_x = (P.nx + P.tile_w - 1u) / P.tile_w;
+  uint32_t tx = x / P.tile_w, ty = row / P.tile_h;
+  uint32_t k = (ty * tiles_x + tx) / P.nranks;  // this rank's k-th tile
+  uint32_t lx = x - tx * P.tile_w, ly = row - ty * P.tile_h;
+  uint32_t b = (ly >> 3) * (P.tile_w >> 3) + (lx >> 3);
+  return k * (P.tile_w * P.tile_h) + b * 64u + (ly & 7u) * 8u + (lx & 7u);
+}
+
+// second pass of the chunk mode: ordered fold of the per-sample colours (vec3.rs:195-203, lib.rs:374)
+__global__ void fold_samples_kernel(DevParams P, ChunkMode cm, float* __restrict__ out) {
+  uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= cm.pix_work) return;
+  uint32_t x, row;
+  if (!work_to_pixel(P, w, x, row)) return;
+  V3 col = mk(0.f, 0.f, 0.f);
+  for (uint32_t s = 0; s < P.ns; s++) {
+    const float* c = cm.scratch + 3ull * ((size_t)s * cm.pix_work + w);
+    col = vadd(col, mk(c[0], c[1], c[2]));
+  }
+  col = sdiv(col, (float)P.ns);
+  float* o = out + 3ull * ((size_t)row * P.nx + x);
+  o[0] = col.x, o[1] = col.y, o[2] = col.z;
+}
+
+struct PoolTuning {
+  uint32_t refill_min;   // idle lanes before the wave services (finish / shade / refill)
+  uint32_t sphere_min;   // parked lanes before a sphere pass
+  uint32_t box_leave;    // lanes leaving the BOX state before a box run re-evaluates the schedule
+};
+
+// dynamic LDS bytes for a workgroup of `waves` waves
+inline size_t pool_lds_bytes(uint32_t n_prog, uint32_t n_mat, uint32_t waves, bool stage_program) {
+  size_t b = stage_program ? ((size_t)n_prog * 32 + (size_t)n_mat * 32) : 0;
+  b += (size_t)waves * POOL * POOL_FIELDS * 4;  // slots
+  b += (size_t)waves * POOL * 2 * 4;            // T-list + S-list
+  return b;
+}
+
+template <bool USE_LDS, bool COUNT>
+__global__ __launch_bounds__(512) void render_lean_pool(DevScene sc, DevCamera cam, DevParams P,
+                                                        float* __restrict__ out, uint32_t total_work,
+                                                        uint32_t* __restrict__ queue, unsigned long long* counters,
+                                                        PoolTuning tune, ChunkMode cm) {
+  extern __shared__ uint4 s_mem[];
+  const uint32_t n_prog = sc.n_prog;
+  const uint32_t staged = USE_LDS ? 2u * n_prog + 2u * sc.n_mat : 0u;  // uint4 units
+  if (USE_LDS) {
+    for (uint32_t i = threadIdx.x; i < n_prog; i += blockDim.x) {
+      s_mem[i] = sc.lo[i];
+      s_mem[n_prog + i] = sc.hi[i];
+    }
+    for (uint32_t i = threadIdx.x; i < 2u * sc.n_mat; i += blockDim.x) s_mem[2u * n_prog + i] = sc.mat[i];
+  }
+#define RT_FETCH_LO(pc_) (USE_LDS ? s_mem[(pc_)] : sc.lo[(pc_)])
+#define RT_FETCH_HI(pc_) (USE_LDS ? s_mem[n_prog + (pc_)] : sc.hi[(pc_)])
+#define RT_FETCH_MAT(i_) (USE_LDS ? s_mem[2u * n_prog + (i_)] : sc.mat[(i_)])
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, n_waves = blockDim.x >> 6;
+  uint32_t* pool_base = reinterpret_cast<uint32_t*>(s_mem + staged);
+  uint32_t* slot = pool_base + wave * (POOL * POOL_FIELDS);
+  float* slotf = reinterpret_cast<float*>(slot);
+  uint32_t* tlist = pool_base + n_waves * (POOL * POOL_FIELDS) + wave * (2u * POOL);
+  uint32_t* slist = tlist + POOL;
+#define SLOT_U(f_, j_) slot[(f_)*POOL + (j_)]
+#define SLOT_F(f_, j_) slotf[(f_)*POOL + (j_)]
+  // all slots start as "need a pixel", all on the S-list
+  for (uint32_t j = lane; j < POOL; j += 64u) {
+    SLOT_U(PF_BEST_PC, j) = SLOT_NEED_PIXEL;
+    slist[j] = j;
+  }
+  __syncthreads();  // program staged, pools initialised (the only workgroup barrier)
+
+  const uint64_t seed = ((uint64_t)P.seed_hi << 32) | P.seed_lo;
+  const float t_near = P.t_near;
+  uint32_t t_count = 0, s_count = POOL, n_dead = 0;  // wave-uniform list sizes / retired slots
+
+  // ---- per-lane traversal state ---------------------------------------------------------------
+  uint32_t my_slot = 0;
+  bool have_ray = false;  // lane holds a ray (traversing or parked at a SPHERE record)
+  V3 o = mk(0.f, 0.f, 0.f), d = o, inv = o;
+  uint32_t pc = 0, best_pc = NO_HIT;
+  float best = F32_MAX;
+  uint4 cur_lo = make_uint4(0, 0, 0, 0), cur_hi = make_uint4(0, 0, 0, OP_END);
+  Counts cnt = {0, 0, 0, 0};
+  uint32_t total_draws = 0;
+  uint32_t n_box_it = 0, n_box_lanes = 0, n_sph_it = 0, n_sph_lanes = 0, n_shade = 0, n_shade_lanes = 0, n_refill = 0;
+
+  for (;;) {
+    uint32_t op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
+    const uint64_t m_box = __builtin_amdgcn_ballot_w64(op == OP_BOX);
+    const uint64_t m_sph = __builtin_amdgcn_ballot_w64(op == OP_SPHERE);
+    const uint32_t n_busy = (uint32_t)__builtin_popcountll(m_box | m_sph);
+    // ============================== SERVICE ======================================================
+    if (64u - n_busy >= tune.refill_min || n_busy == 0) {
+      // (1) finish: rays that reached END hand their result to their slot and join the S-list
+      {
+        const bool fin = have_ray && op == OP_END;
+        const uint64_t m_fin = __builtin_amdgcn_ballot_w64(fin);
+        if (fin) {
+          SLOT_F(PF_BEST, my_slot) = best;
+          SLOT_U(PF_BEST_PC, my_slot) = best_pc;
+          slist[s_count + lane_rank(m_fin)] = my_slot;
+          have_ray = false;
+        }
+        s_count += (uint32_t)__builtin_popcountll(m_fin);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      // (2) shade: a full-width pass whenever 64 slots wait, or when nothing else can make progress
+      while (s_count >= 64u || (s_count > 0 && t_count == 0 && n_busy == 0)) {
+        const uint32_t take = s_count < 64u ? s_count : 64u;
+        s_count -= take;
+        if (COUNT) n_shade++, n_shade_lanes += take;
+        uint32_t st = ST_DEAD, j = 0;
+        V3 so = mk(0.f, 0.f, 0.f), sd = so, strength = so, accum = so, col = so;
+        uint32_t bounces = 0, s = 0, x = 0, row = 0;
+        if (lane < take) {
+          j = slist[s_count + lane];
+          const uint32_t bpc = SLOT_U(PF_BEST_PC, j);
+          if (bpc == SLOT_NEED_PIXEL) {
+            st = ST_NEED_PIXEL;
+          } else {
+            st = ST_SHADE;
+            so = mk(SLOT_F(PF_O, j), SLOT_F(PF_O + 1, j), SLOT_F(PF_O + 2, j));
+            sd = mk(SLOT_F(PF_D, j), SLOT_F(PF_D + 1, j), SLOT_F(PF_D + 2, j));
+            strength = mk(SLOT_F(PF_STRENGTH, j), SLOT_F(PF_STRENGTH + 1, j), SLOT_F(PF_STRENGTH + 2, j));
+            accum = mk(SLOT_F(PF_ACCUM, j), SLOT_F(PF_ACCUM + 1, j), SLOT_F(PF_ACCUM + 2, j));
+            col = mk(SLOT_F(PF_COL, j), SLOT_F(PF_COL + 1, j), SLOT_F(PF_COL + 2, j));
+            bounces = SLOT_U(PF_BOUNCES, j), s = SLOT_U(PF_SAMPLE, j);
+            const uint32_t xy = SLOT_U(PF_XY, j);
+            x = xy & 0xffffu, row = xy >> 16;
+            const float hb = SLOT_F(PF_BEST, j);
+            // ---------------- color() loop body, lib.rs:73-97 ----------------
+            SampleRng rng;
+            rng.init(seed, (P.ny - 1u - row) * P.nx + x, s);
+            rng.set_event(bounces + 1u);
+            bool ended = true;
+            V3 result = mk(0.f, 0.f, 0.f);  // lib.rs:100: a miss is black, accum is discarded
+            if (bpc != NO_HIT) {
+              if (COUNT) cnt.shaded++;
+              const uint4 plo = RT_FETCH_LO(bpc), phi = RT_FETCH_HI(bpc);
+              V3 off = mk(u2f(plo.x), u2f(plo.y), u2f(plo.z));
+              V3 lo_o = so;
+              if (phi.w & F_TRANSLATE) lo_o = vsub(so, off);
+              V3 hp = vadd(lo_o, smul(hb, sd));
+              V3 hn = sdiv(hp, u2f(plo.w));
+              if (phi.w & F_TRANSLATE) hp = vadd(hp, off);
+              if (phi.w & F_FLIP) hn = vneg(hn);
+              const uint4 mlo = RT_FETCH_MAT(2u * phi.z), mhi = RT_FETCH_MAT(2u * phi.z + 1u);
+              const uint32_t kind = mhi.w & 0xffu;
+              const float param = u2f(mlo.w);
+              const V3 mcol = mk(u2f(mlo.x), u2f(mlo.y), u2f(mlo.z));
+              V3 emitted = mk(0.f, 0.f, 0.f);
+              if (kind == MAT_DIFFUSE_LIGHT) emitted = smul(param, mcol);
+              accum = vadd(accum, vmul(strength, emitted));
+              V3 nd = mk(0.f, 0.f, 0.f), att = mcol;
+              bool scattered = true;
+              V3 rs = mk(0.f, 0.f, 0.f);
+              if (kind == MAT_LAMBERTIAN || kind == MAT_METAL || kind == MAT_ISOTROPIC) rs = in_unit_sphere(rng);
+              if (kind == MAT_LAMBERTIAN) {
+                V3 target = vadd(vadd(hp, hn), rs);
+                nd = vsub(target, hp);
+              } else if (kind == MAT_METAL) {
+                V3 refl = reflect(vunit(sd), hn);
+                nd = vadd(refl, smul(param, rs));
+                scattered = vdot(nd, hn) > 0.f;
+              } else if (kind == MAT_DIELECTRIC) {
+                V3 outward;
+                float ni_over_nt, cosine;
+                float dn = vdot(sd, hn);
+                if (dn > 0.f) {
+                  outward = vneg(hn);
+                  ni_over_nt = param;
+                  cosine = param * dn / vlen(sd);
+                } else {
+                  outward = hn;
+                  ni_over_nt = 1.0f / param;
+                  cosine = -dn / vlen(sd);
+                }
+                V3 uv = vunit(sd);
+                float dt = vdot(uv, outward);
+                float disc = 1.0f - ni_over_nt * ni_over_nt * (1.f - dt * dt);
+                bool refracted = disc > 0.f;
+                if (refracted) {
+                  nd = vsub(smul(ni_over_nt, vsub(uv, smul(dt, outward))), smul(__builtin_sqrtf(disc), outward));
+                  refracted = rng.gen_f32() >= schlick(cosine, param);
+                }
+                if (!refracted) nd = reflect(sd, hn);
+                att = splat(1.f);
+              } else if (kind == MAT_DIFFUSE_LIGHT) {
+                scattered = false;
+              } else {
+                nd = rs;
+              }
+              result = accum;
+              if (scattered) {
+                so = hp, sd = nd;
+                strength = vmul(strength, att);
+                if (bounces != P.max_bounces) {
+                  bounces += 1;
+                  ended = false;
+                }
+              }
+            }
+            if (COUNT) total_draws += rng.draws;
+            if (ended) {
+              if (cm.scratch) {  // chunk mode: park the sample colour, folded in order afterwards
+                float* sp = cm.scratch + 3ull * ((size_t)s * cm.pix_work + pixel_to_work(P, x, row));
+                sp[0] = result.x, sp[1] = result.y, sp[2] = result.z;
+              } else {
+                col = vadd(col, result);
+              }
+              s++;
+              if (s == P.ns || (cm.scratch && s % cm.chunk == 0u)) {
+                if (!cm.scratch) {
+                  V3 px = sdiv(col, (float)P.ns);
+                  float* op_ = out + 3ull * ((size_t)row * P.nx + x);
+                  op_[0] = px.x, op_[1] = px.y, op_[2] = px.z;
+                }
+                st = ST_NEED_PIXEL;
+              } else {
+                st = ST_GEN;
+              }
+            } else {
+              st = ST_TRAV;
+            }
+          }
+        }
+        // next pixel from the global work counter (one atomic per wave per round)
+        for (;;) {
+          uint64_t need = __builtin_amdgcn_ballot_w64(st == ST_NEED_PIXEL);
+          if (need == 0) break;
+          uint32_t base = 0;
+          if (lane == (uint32_t)__builtin_ctzll(need)) base = atomicAdd(queue, (uint32_t)__builtin_popcountll(need));
+          base = __builtin_amdgcn_readlane(base, __builtin_ctzll(need));
+          if (st == ST_NEED_PIXEL) {
+            uint32_t w = base + lane_rank(need);
+            if (w >= total_work) {
+              st = ST_DEAD;
+            } else {
+              uint32_t first = 0;
+              if (cm.scratch) {  // work item = (chunk, pixel), pixel-minor so a wave's grab stays coherent
+                const uint32_t c = w / cm.pix_work;
+                w -= c * cm.pix_work;
+                first = c * cm.chunk;
+              }
+              if (work_to_pixel(P, w, x, row) && first < P.ns) {
+                s = first;
+                col = mk(0.f, 0.f, 0.f);
+                st = ST_GEN;
+              }
+            }
+          }
+        }
+        if (st == ST_GEN) {  // par_cast closure, lib.rs:366-371 (event 0)
+          const uint32_t y = P.ny - 1u - row;
+          SampleRng rng;
+          rng.init(seed, y * P.nx + x, s);
+          float u = ((float)x + rng.gen_f32()) / (float)P.nx;
+          float v = ((float)y + rng.gen_f32()) / (float)P.ny;
+          float time;
+          get_ray(cam, u, v, rng, so, sd, time);
+          accum = mk(0.f, 0.f, 0.f), strength = splat(1.f), bounces = 0;
+          if (COUNT) total_draws += rng.draws;
+          st = ST_TRAV;
+        }
+        // write the paths back; live ones join the T-list
+        const bool live = st == ST_TRAV;
+        const uint64_t m_live = __builtin_amdgcn_ballot_w64(live);
+        if (live) {
+          SLOT_F(PF_O, j) = so.x, SLOT_F(PF_O + 1, j) = so.y, SLOT_F(PF_O + 2, j) = so.z;
+          SLOT_F(PF_D, j) = sd.x, SLOT_F(PF_D + 1, j) = sd.y, SLOT_F(PF_D + 2, j) = sd.z;
+          SLOT_F(PF_STRENGTH, j) = strength.x, SLOT_F(PF_STRENGTH + 1, j) = strength.y, SLOT_F(PF_STRENGTH + 2, j) = strength.z;
+          SLOT_F(PF_ACCUM, j) = accum.x, SLOT_F(PF_ACCUM + 1, j) = accum.y, SLOT_F(PF_ACCUM + 2, j) = accum.z;
+          SLOT_F(PF_COL, j) = col.x, SLOT_F(PF_COL + 1, j) = col.y, SLOT_F(PF_COL + 2, j) = col.z;
+          SLOT_U(PF_BOUNCES, j) = bounces, SLOT_U(PF_SAMPLE, j) = s;
+          SLOT_U(PF_XY, j) = x | (row << 16);
+          tlist[t_count + lane_rank(m_live)] = j;
+          if (COUNT) cnt.rays++;
+        }
+        t_count += (uint32_t)__builtin_popcountll(m_live);
+        n_dead += take - (uint32_t)__builtin_popcountll(m_live);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      }
+      // (3) refill idle lanes from the T-list
+      {
+        const uint64_t m_idle = __builtin_amdgcn_ballot_w64(!have_ray);
+        const uint32_t n_idle = (uint32_t)__builtin_popcountll(m_idle);
+        const uint32_t got = n_idle < t_count ? n_idle : t_count;
+        if (got) {
+          const uint32_t r = lane_rank(m_idle);
+          if (!have_ray && r < got) {
+            my_slot = tlist[t_count - 1u - r];
+            o = mk(SLOT_F(PF_O, my_slot), SLOT_F(PF_O + 1, my_slot), SLOT_F(PF_O + 2, my_slot));
+            d = mk(SLOT_F(PF_D, my_slot), SLOT_F(PF_D + 1, my_slot), SLOT_F(PF_D + 2, my_slot));
+            inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);  // aabb.rs:17
+            pc = 0, best = F32_MAX, best_pc = NO_HIT;
+            cur_lo = RT_FETCH_LO(0), cur_hi = RT_FETCH_HI(0);
+            have_ray = true;
+          }
+          t_count -= got;
+          if (COUNT) n_refill++;
+        }
+      }
+      if (n_dead == POOL) break;  // every slot retired: this wave is done
+      if (__builtin_amdgcn_ballot_w64(have_ray) == 0) continue;  // nothing to traverse yet: service again
+      op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
+    }
+    // ============================== TRAVERSE ======================================================
+    const uint64_t b_box = __builtin_amdgcn_ballot_w64(op == OP_BOX);
+    const uint64_t b_sph = __builtin_amdgcn_ballot_w64(op == OP_SPHERE);
+    if (b_box != 0 && (uint32_t)__builtin_popcountll(b_sph) < tune.sphere_min) {
+      // box run: tight loop, schedule re-evaluated once `box_leave` lanes have left the BOX state
+      const uint32_t n0 = (uint32_t)__builtin_popcountll(b_box);
+      const uint32_t floor_lanes = n0 > tune.box_leave ? n0 - tune.box_leave : 0u;
+      uint32_t n_now;
+      do {
+        if (COUNT) n_box_it++;
+        if (op == OP_BOX) {  // Aabb::hit, aabb.rs:16-27
+          if (COUNT) cnt.aabb++;
+          float t0x = (u2f(cur_lo.x) - o.x) * inv.x, t1x = (u2f(cur_lo.w) - o.x) * inv.x;
+          float t0y = (u2f(cur_lo.y) - o.y) * inv.y, t1y = (u2f(cur_hi.x) - o.y) * inv.y;
+          float t0z = (u2f(cur_lo.z) - o.z) * inv.z, t1z = (u2f(cur_hi.y) - o.z) * inv.z;
+          float ax = inv.x < 0.f ? t1x : t0x, bx = inv.x < 0.f ? t0x : t1x;
+          float ay = inv.y < 0.f ? t1y : t0y, by = inv.y < 0.f ? t0y : t1y;
+          float az = inv.z < 0.f ? t1z : t0z, bz = inv.z < 0.f ? t0z : t1z;
+          float start = rs_max(t_near, rs_max(rs_max(ax, ay), az));
+          float end = rs_min(best, rs_min(rs_min(bx, by), bz));
+          pc = (end > start) ? pc + 1u : cur_hi.z;
+          cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc);
+          op = cur_hi.w & 0xffu;
+        }
+        n_now = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op == OP_BOX));
+        if (COUNT) n_box_lanes += n_now;
+      } while (n_now > floor_lanes);
+    } else if (b_sph != 0) {
+      if (COUNT) n_sph_it++, n_sph_lanes += (uint32_t)__builtin_popcountll(b_sph);
+      if (op == OP_SPHERE) {  // Sphere::hit, object.rs:84-111 (+ Translate :275)
+        if (COUNT) cnt.prim++;
+        V3 lo_o = o;
+        if (cur_hi.w & F_TRANSLATE) lo_o = vsub(o, mk(u2f(cur_lo.x), u2f(cur_lo.y), u2f(cur_lo.z)));
+        float t;
+        if (sphere_hit_t(lo_o, d, u2f(cur_lo.w), t_near, best, t)) {
+          best = t;
+          best_pc = pc;
+        }
+        pc++;
+        cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc);
+      }
+    }
+  }
+  if (COUNT) {
+    atomicAdd(&counters[0], (unsigned long long)cnt.aabb);
+    atomicAdd(&counters[1], (unsigned long long)cnt.prim);
+    atomicAdd(&counters[2], (unsigned long long)cnt.shaded);
+    atomicAdd(&counters[3], (unsigned long long)cnt.rays);
+    atomicAdd(&counters[4], (unsigned long long)total_draws);
+    if (lane == 0) {
+      unsigned long long* sched = counters + 8;
+      atomicAdd(&sched[0], (unsigned long long)n_box_it), atomicAdd(&sched[1], (unsigned long long)n_box_lanes);
+      atomicAdd(&sched[2], (unsigned long long)n_sph_it), atomicAdd(&sched[3], (unsigned long long)n_sph_lanes);
+      atomicAdd(&sched[4], (unsigned long long)n_shade), atomicAdd(&sched[5], (unsigned long long)n_shade_lanes);
+      atomicAdd(&sched[6], (unsigned long long)n_refill);
+    }
+  }
+#undef RT_FETCH_LO
+#undef RT_FETCH_HI
+#undef RT_FETCH_MAT
+#undef SLOT_U
+#undef SLOT_F
+}
+
+}  // namespace rtg

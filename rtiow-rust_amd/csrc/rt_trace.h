@@ -14,6 +14,7 @@ struct DevScene {
   const float4* perlin_vecs; // 256 gradients (perlin.rs VECS)
   const uint8_t* perlin_perm;// PERM_X | PERM_Y | PERM_Z, 3 x 256
   uint32_t n_prog;
+  uint32_t n_mat;
 };
 
 struct DevCamera {  // camera.rs:6-15
@@ -312,6 +313,7 @@ RT_DEV V3 color(const DevScene& sc, V3 o, V3 d, float time, const DevParams& P, 
   V3 strength = splat(1.f);
   uint32_t bounces = 0;
   HitRec hit;
+  rng.set_event(1);
   while (hit_top<FEAT, COUNT>(sc, o, d, time, P.t_near, rng, hit, cnt)) {
     if (COUNT) cnt.shaded++;
     const uint4 mlo = sc.mat[2 * hit.mat], mhi = sc.mat[2 * hit.mat + 1];
@@ -372,6 +374,7 @@ RT_DEV V3 color(const DevScene& sc, V3 o, V3 d, float time, const DevParams& P, 
       return accum;
     }
     bounces += 1;
+    rng.set_event(bounces + 1);
   }
   bounces_out = bounces;
   return mk(0.f, 0.f, 0.f);  // lib.rs:100

@@ -5,11 +5,15 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "../../include/rtiow_gpu.h"
+#include "rt_persistent.h"
+#include "rt_pool.h"
 #include "rt_trace.h"
 #include "scene_builder.h"
 
@@ -68,6 +72,7 @@ __global__ void debug_hit_top_kernel(DevScene sc, uint32_t n, const float* rays,
   const float* r = rays + 7ull * i;
   SampleRng rng;
   rng.init(((uint64_t)seed_hi << 32) | seed_lo, i, 0);
+  rng.set_event(1);
   HitRec h;
   Counts cnt = {0, 0, 0, 0};
   bool hit = hit_top<FEAT, false>(sc, mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5]), r[6], t_near, rng, h, cnt);
@@ -138,13 +143,131 @@ struct rtg_scene {
   uint32_t n_prog = 0, n_mat = 0, n_tex = 0;
   uint64_t bytes = 0;
   void* buffers[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  unsigned long long* d_counters = nullptr;
+  unsigned long long* d_counters = nullptr;  // [0..4] N/P/H/rays/draws, [7] = work-queue head (persistent kernel)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int num_cus = 0;
+  float* d_scratch = nullptr;  // chunk-mode per-sample colours
+  size_t scratch_bytes = 0;
+  int force_chunks = 0;        // RTG_CHUNKS: 0 = automatic
+  // lean scenes: 3 = ray-pool kernel (rt_pool.h), 2 = persistent single-wave regeneration (rt_persistent.h),
+  // 1 = one-lane-per-pixel baseline (rt_trace.h).  Non-lean scenes always use 1.
+  int kernel_version = 3;
+  PoolTuning pool_tune{12, 16, 16};
+  Tuning tune{24, 16, 8};
+  int block_threads = 512, wg_per_cu = 0;  // 0 = ask the occupancy API
 };
 
+static uint64_t owned_pixels(const DevParams& d);
+
+// Lean scenes: persistent wavefronts pulling pixels from a work counter (rt_persistent.h).
 template <bool COUNT>
-static void launch_render(const rtg_scene* s, const DevCamera& cam, const DevParams& d, float* d_out,
+static hipError_t launch_persistent(const rtg_scene* s, const DevCamera& cam, const DevParams& d, float* d_out,
+                                    hipStream_t stream) {
+  uint32_t tiles_x = (d.nx + d.tile_w - 1) / d.tile_w, tiles_y = (d.ny + d.tile_h - 1) / d.tile_h;
+  uint32_t tiles = tiles_x * tiles_y;
+  uint32_t owned = tiles > d.rank ? (tiles - d.rank + d.nranks - 1) / d.nranks : 0;
+  uint64_t total_work = (uint64_t)owned * d.tile_w * d.tile_h;
+  if (total_work > 0xfffffffeull) return hipErrorInvalidValue;
+  uint32_t* queue = (uint32_t*)(s->d_counters + 7);
+  hipError_t e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream);  // re-initialise every call
+  if (e != hipSuccess) return e;
+  size_t lds = (size_t)s->n_prog * 32 + (size_t)s->n_mat * 32;
+  bool use_lds = lds <= 64 * 1024;
+  auto kernel = use_lds ? render_lean_persistent<true, COUNT> : render_lean_persistent<false, COUNT>;
+  if (!use_lds) lds = 0;
+  int per_cu = s->wg_per_cu;
+  const int bt = s->block_threads;
+  if (per_cu <= 0) {
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, bt, lds);
+    if (e != hipSuccess) return e;
+  }
+  if (per_cu < 1) per_cu = 1;
+  uint64_t want = (total_work + bt - 1) / bt;
+  uint32_t grid = (uint32_t)std::min<uint64_t>(want ? want : 1, (uint64_t)s->num_cus * per_cu);
+  if (getenv("RTG_VERBOSE")) fprintf(stderr, "[rtg] persistent: grid %u x %d threads, %d WG/CU, lds %zu B\n", grid, bt, per_cu, lds);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(bt), lds, stream, s->dev, cam, d, d_out, (uint32_t)total_work, queue,
+                     s->d_counters, s->tune);
+  return hipGetLastError();
+}
+
+// Lean scenes, ray-pool kernel (rt_pool.h): one persistent 512-thread workgroup per CU.
+template <bool COUNT>
+static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParams& d, float* d_out,
+                              hipStream_t stream) {
+  uint32_t tiles_x = (d.nx + d.tile_w - 1) / d.tile_w, tiles_y = (d.ny + d.tile_h - 1) / d.tile_h;
+  uint32_t tiles = tiles_x * tiles_y;
+  uint32_t owned = tiles > d.rank ? (tiles - d.rank + d.nranks - 1) / d.nranks : 0;
+  const uint64_t pix_work = (uint64_t)owned * d.tile_w * d.tile_h;
+  const int bt = s->block_threads;
+  const uint32_t waves = (uint32_t)bt / 64;
+  // chunk mode when the rank owns too few pixels to keep every path slot of the chip busy
+  ChunkMode cm{nullptr, d.ns, 1, (uint32_t)pix_work};
+  {
+    // Default: one sample per work item.  Work items are then ~100x more numerous than path slots, so
+    // the end-of-frame tail (slots finishing their last item while the queue is empty) is negligible;
+    // measured on C2: 40.6 ms with one pixel (50 samples) per item, 23.5 ms with one sample per item.
+    uint64_t n_chunks = d.ns;
+    if (s->force_chunks > 0) n_chunks = (uint64_t)s->force_chunks;
+    if (n_chunks > d.ns) n_chunks = d.ns;
+    const uint64_t need = pix_work * d.ns * 3 * sizeof(float);
+    if (n_chunks > 1 && need <= (16ull << 30) && pix_work * n_chunks <= 0xfffffffeull) {
+      if (need > s->scratch_bytes) {
+        if (s->d_scratch) (void)hipFree(s->d_scratch);
+        s->d_scratch = nullptr, s->scratch_bytes = 0;
+        hipError_t ea = hipMalloc((void**)&s->d_scratch, need);
+        if (ea != hipSuccess) return ea;
+        s->scratch_bytes = need;
+      }
+      cm.chunk = (uint32_t)((d.ns + n_chunks - 1) / n_chunks);
+      cm.n_chunks = (uint32_t)((d.ns + cm.chunk - 1) / cm.chunk);
+      cm.scratch = s->d_scratch;
+    }
+  }
+  uint64_t total_work = pix_work * cm.n_chunks;
+  if (total_work > 0xfffffffeull) return hipErrorInvalidValue;
+  uint32_t* queue = (uint32_t*)(s->d_counters + 7);
+  hipError_t e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream);  // re-initialise every call
+  if (e != hipSuccess) return e;
+  const size_t lds_limit = 160 * 1024;
+  bool use_lds = pool_lds_bytes(s->n_prog, s->n_mat, waves, true) <= lds_limit;
+  size_t lds = pool_lds_bytes(s->n_prog, s->n_mat, waves, use_lds);
+  auto kernel = use_lds ? render_lean_pool<true, COUNT> : render_lean_pool<false, COUNT>;
+  e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  int per_cu = s->wg_per_cu;
+  if (per_cu <= 0) {
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, bt, lds);
+    if (e != hipSuccess) return e;
+  }
+  if (per_cu < 1) per_cu = 1;
+  // a wave keeps POOL paths in flight; do not launch more waves than there is work for
+  uint64_t want = (total_work + (uint64_t)waves * POOL - 1) / ((uint64_t)waves * POOL);
+  uint32_t grid = (uint32_t)std::min<uint64_t>(want ? want : 1, (uint64_t)s->num_cus * per_cu);
+  if (getenv("RTG_VERBOSE"))
+    fprintf(stderr, "[rtg] pool: grid %u x %d threads, %d WG/CU, lds %zu B (program staged: %d), %u chunk(s) of %u samples\n", grid,
+            bt, per_cu, lds, (int)use_lds, cm.n_chunks, cm.chunk);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(bt), lds, stream, s->dev, cam, d, d_out, (uint32_t)total_work, queue,
+                     s->d_counters, s->pool_tune, cm);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (cm.scratch) {
+    hipLaunchKernelGGL(fold_samples_kernel, dim3((uint32_t)((pix_work + 255) / 256)), dim3(256), 0, stream, d, cm, d_out);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+template <bool COUNT>
+static void launch_render(rtg_scene* s, const DevCamera& cam, const DevParams& d, float* d_out,
                           hipStream_t stream) {
+  if (s->features == 0 && s->kernel_version >= 3 && d.nx <= 0xffffu && d.ny <= 0xffffu) {
+    (void)launch_pool<COUNT>(s, cam, d, d_out, stream);
+    return;
+  }
+  if (s->features == 0 && s->kernel_version >= 2) {
+    (void)launch_persistent<COUNT>(s, cam, d, d_out, stream);
+    return;
+  }
   uint32_t nbx = (d.nx + 15) / 16, nby = (d.ny + 15) / 16;
   dim3 grid(nbx * nby), block(256);
   if (s->features == 0)
@@ -407,6 +530,7 @@ void rtg_scene_destroy(rtg_scene* s) {
   for (void* p : s->buffers)
     if (p) (void)hipFree(p);
   if (s->d_counters) (void)hipFree(s->d_counters);
+  if (s->d_scratch) (void)hipFree(s->d_scratch);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   delete s;
@@ -448,7 +572,20 @@ int rtg_scene_create(rtg_builder* b, const rtg_id* world, size_t n, int device, 
   s->dev.perlin_vecs = (const float4*)s->buffers[4];
   s->dev.perlin_perm = (const uint8_t*)s->buffers[5];
   s->dev.n_prog = s->n_prog;
-  if (hipMalloc((void**)&s->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
+  s->dev.n_mat = s->n_mat;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->num_cus = prop.multiProcessorCount;
+  if (s->num_cus <= 0) s->num_cus = 256;
+  if (const char* kv = getenv("RTG_KERNEL")) s->kernel_version = atoi(kv);  // A/B switches for measurements
+  if (const char* kv = getenv("RTG_CHUNKS")) s->force_chunks = atoi(kv);
+  if (const char* kv = getenv("RTG_BLOCK")) s->block_threads = atoi(kv);
+  if (const char* kv = getenv("RTG_WG_PER_CU")) s->wg_per_cu = atoi(kv);
+  if (const char* kv = getenv("RTG_REGEN_MIN")) s->tune.regen_min = (uint32_t)atoi(kv);
+  if (const char* kv = getenv("RTG_SPHERE_MIN")) s->tune.sphere_min = (uint32_t)atoi(kv);
+  if (const char* kv = getenv("RTG_BOX_LEAVE")) s->tune.box_leave = s->pool_tune.box_leave = (uint32_t)atoi(kv);
+  if (const char* kv = getenv("RTG_REFILL_MIN")) s->pool_tune.refill_min = (uint32_t)atoi(kv);
+  if (const char* kv = getenv("RTG_SPHERE_MIN")) s->pool_tune.sphere_min = (uint32_t)atoi(kv);
+  if (hipMalloc((void**)&s->d_counters, 24 * sizeof(unsigned long long)) != hipSuccess ||
       hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
     rtg_scene_destroy(s);
     return fail(RTG_ERR_DEVICE, "scene: counter/event allocation failed");
@@ -521,7 +658,10 @@ int rtg_par_cast_device(rtg_scene* s, const rtg_camera* camera, const rtg_params
   hipStream_t stream = (hipStream_t)hip_stream;
   DevCamera cam = to_dev(camera);
   bool count = stats && (params->flags & RTG_FLAG_COUNTERS);
-  if (count) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), stream));
+  if (count) {
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, 7 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(s->d_counters + 8, 0, 16 * sizeof(unsigned long long), stream));
+  }
   if (stats) HIP_TRY(hipEventRecord(s->ev0, stream));
   if (count) launch_render<true>(s, cam, d, d_out, stream);
   else launch_render<false>(s, cam, d, d_out, stream);
@@ -536,6 +676,23 @@ int rtg_par_cast_device(rtg_scene* s, const rtg_camera* camera, const rtg_params
     unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (count) HIP_TRY(hipMemcpy(h, s->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     stats->aabb_tests = h[0], stats->prim_tests = h[1], stats->shaded_hits = h[2], stats->rays = h[3], stats->draws = h[4];
+    if (count && getenv("RTG_VERBOSE")) {
+      unsigned long long q[16];
+      HIP_TRY(hipMemcpy(q, s->d_counters + 8, sizeof(q), hipMemcpyDeviceToHost));
+      double tt = (double)(q[8] + q[9] + q[10] + q[11]);
+      fprintf(stderr, "[rtg] wave-time shares (s_memtime, instrumented variant): shade %.1f%% gen+pull %.1f%% box %.1f%% sphere %.1f%%; "
+              "per pass: shade+... %.0f, gen %.0f, box %.0f, sphere %.0f ticks\n", 100 * q[8] / tt, 100 * q[9] / tt, 100 * q[10] / tt,
+              100 * q[11] / tt, q[4] ? (double)q[8] / q[4] : 0., q[4] ? (double)q[9] / q[4] : 0., q[0] ? (double)q[10] / q[0] : 0.,
+              q[2] ? (double)q[11] / q[2] : 0.);
+      if (s->kernel_version >= 3)
+        fprintf(stderr, "[rtg] pool schedule: box steps %llu (avg %.1f lanes), sphere passes %llu (avg %.1f lanes), shade passes %llu "
+                "(avg %.1f lanes), refills %llu\n", q[0], q[0] ? (double)q[1] / q[0] : 0.0, q[2], q[2] ? (double)q[3] / q[2] : 0.0,
+                q[4], q[4] ? (double)q[5] / q[4] : 0.0, q[6]);
+      else
+      fprintf(stderr, "[rtg] schedule: box passes %llu (avg %.1f lanes), sphere passes %llu (avg %.1f lanes), regen passes %llu "
+              "(avg %.1f shade + %.1f gen lanes)\n", q[0], q[0] ? (double)q[1] / q[0] : 0.0, q[2], q[2] ? (double)q[3] / q[2] : 0.0,
+              q[4], q[4] ? (double)q[5] / q[4] : 0.0, q[4] ? (double)q[6] / q[4] : 0.0);
+    }
   }
   return RTG_OK;
 }

@@ -210,3 +210,28 @@ def test_cxx_crate_mirror_example(pkg, gpu, tmp_path):
         out = subprocess.run([exe, which, "40", "24", "6"], check=True, capture_output=True, text=True).stdout
         sg, cam, nx, ny, _ = build_case(pkg, gpu, case, 40, 24)
         assert out == pkg.ppm.format_ppm(sg.par_cast(cam, nx, ny, 6)), which
+
+
+@pytest.mark.parametrize("env", [
+    {"RTG_KERNEL": "1"},                       # one-lane-per-pixel baseline kernel
+    {"RTG_KERNEL": "2"},                       # persistent single-wave regeneration kernel
+    {"RTG_KERNEL": "3", "RTG_CHUNKS": "1"},    # ray-pool kernel, a slot folds its own pixel
+    {"RTG_KERNEL": "3", "RTG_CHUNKS": "3"},    # ray-pool kernel, 3 sample chunks per pixel + fold kernel
+    {"RTG_KERNEL": "3"},                       # ray-pool kernel, automatic chunking
+    {"RTG_KERNEL": "3", "RTG_REFILL_MIN": "1", "RTG_SPHERE_MIN": "1", "RTG_BOX_LEAVE": "1"},   # degenerate schedules
+    {"RTG_KERNEL": "3", "RTG_REFILL_MIN": "64", "RTG_SPHERE_MIN": "64", "RTG_BOX_LEAVE": "64"},
+])
+def test_every_kernel_variant_and_schedule_gives_the_same_bits(pkg, gpu, oracle, env, monkeypatch):
+    """The schedule (kernel generation, chunking, thresholds) must never change a bit."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)   # read by rtg_scene_create
+    for name, nx, ny, ns in (("book1", 72, 40, 7), ("book1_list", 24, 16, 4)):
+        sg, cam_g, _, _, _ = build_case(pkg, gpu, name, nx, ny)
+        so, cam_o, _, _, _ = build_case(pkg, oracle, name, nx, ny)
+        img_o, st_o = so.par_cast(cam_o, nx, ny, ns, stats=True)
+        img_g, st_g = sg.par_cast(cam_g, nx, ny, ns, stats=True)
+        assert_bit_equal(img_g, img_o, "%s %s" % (name, env))
+        for k in ("samples", "aabb_tests", "prim_tests", "shaded_hits", "rays", "draws"):
+            assert st_g[k] == st_o[k], (name, env, k)
+        assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns, rank=1, nranks=3), so.par_cast(cam_o, nx, ny, ns, rank=1, nranks=3),
+                         "%s shard %s" % (name, env))

@@ -20,14 +20,16 @@ def test_philox4x32_10_random123_kat(oracle):
 
 
 def test_sample_stream_layout(oracle):
-    """Stream (seed, pixel, sample): block b = philox(key=seed lo/hi, ctr=(b, sample, pixel, 0)), words in order."""
+    """Stream (seed, pixel, sample, event): block b = philox(key=seed lo/hi, ctr=(b, sample, pixel, event))."""
     seed, pixel, sample = 0x0123456789ABCDEF, 4711, 13
-    out = (C.c_uint32 * 10)()
-    oracle.lib.rto_debug_sample_rng_u32(C.c_uint64(seed), C.c_uint32(pixel), C.c_uint32(sample), C.c_size_t(10), out)
-    expect = []
-    for blk in range(3):
-        expect += philox(oracle, (seed & 0xffffffff, seed >> 32), (blk, sample, pixel, 0))
-    assert [int(x) for x in out] == expect[:10]
+    for event in (0, 1, 7):
+        out = (C.c_uint32 * 10)()
+        oracle.lib.rto_debug_sample_rng_u32(C.c_uint64(seed), C.c_uint32(pixel), C.c_uint32(sample), C.c_uint32(event),
+                                            C.c_size_t(10), out)
+        expect = []
+        for blk in range(3):
+            expect += philox(oracle, (seed & 0xffffffff, seed >> 32), (blk, sample, pixel, event))
+        assert [int(x) for x in out] == expect[:10]
 
 
 def test_mcg128xsl64_kat(oracle):
