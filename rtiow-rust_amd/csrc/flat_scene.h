@@ -25,7 +25,8 @@ namespace rtg {
 
 enum Op : uint32_t {
   OP_END = 0,
-  OP_BOX = 1,     // lo = (min.x, min.y, min.z, max.x)  hi = (max.y, max.z, skip_pc, op)
+  OP_BOX = 1,     // lo = (min.x, max.x, min.y, max.y)  hi = (min.z, max.z, skip_pc, op): per-axis (min,max) pairs sit in
+                  //      adjacent registers so the slab test runs as packed f32 math (v_pk_add_f32 / v_pk_mul_f32)
   OP_SPHERE = 2,  // lo = (off.x, off.y, off.z, radius) hi = (-, -, material, op|flags)
   OP_RECT = 3,    // lo = (k, r0.start, r0.end, r1.start) hi = (r1.end, -, material, op|flags)
   OP_PUSH = 4,    // lo = (a, b, c, -)                   hi = (-, -, matching_pop, op|kind)

@@ -263,9 +263,9 @@ __global__ __launch_bounds__(512) void render_lean_persistent(DevScene sc, DevCa
           if (COUNT) n_box_it++;
           if (op == OP_BOX) {  // Aabb::hit, aabb.rs:16-27
             if (COUNT) cnt.aabb++;
-            float t0x = (u2f(cur_lo.x) - o.x) * inv.x, t1x = (u2f(cur_lo.w) - o.x) * inv.x;
-            float t0y = (u2f(cur_lo.y) - o.y) * inv.y, t1y = (u2f(cur_hi.x) - o.y) * inv.y;
-            float t0z = (u2f(cur_lo.z) - o.z) * inv.z, t1z = (u2f(cur_hi.y) - o.z) * inv.z;
+            float t0x = (u2f(cur_lo.x) - o.x) * inv.x, t1x = (u2f(cur_lo.y) - o.x) * inv.x;
+            float t0y = (u2f(cur_lo.z) - o.y) * inv.y, t1y = (u2f(cur_lo.w) - o.y) * inv.y;
+            float t0z = (u2f(cur_hi.x) - o.z) * inv.z, t1z = (u2f(cur_hi.y) - o.z) * inv.z;
             float ax = inv.x < 0.f ? t1x : t0x, bx = inv.x < 0.f ? t0x : t1x;
             float ay = inv.y < 0.f ? t1y : t0y, by = inv.y < 0.f ? t0y : t1y;
             float az = inv.z < 0.f ? t1z : t0z, bz = inv.z < 0.f ? t0z : t1z;

@@ -27,6 +27,7 @@ namespace rtg {
 
 constexpr uint32_t POOL = 128;           // path slots per wave
 constexpr uint32_t POOL_FIELDS = 20;     // dwords per slot (SoA: field f of slot j at [f * POOL + j])
+constexpr uint32_t WORK_BLOCK = 2048;    // work items a wave reserves per global atomic
 constexpr uint32_t SLOT_NEED_PIXEL = 0xfffffffeu;  // best_pc marker: slot holds no ray yet
 
 enum PoolField : uint32_t {
@@ -77,37 +78,54 @@ struct PoolTuning {
   uint32_t box_leave;    // lanes leaving the BOX state before a box run re-evaluates the schedule
 };
 
-// dynamic LDS bytes for a workgroup of `waves` waves
-inline size_t pool_lds_bytes(uint32_t n_prog, uint32_t n_mat, uint32_t waves, bool stage_program) {
+// dynamic LDS bytes for a workgroup of `waves` waves.  The path slots live either in LDS (80 B x 128 per
+// wave: caps a CU at 8 waves) or in a per-wave SoA region of global memory (L2-resident; a field access
+// of 64 lanes touches at most 4 cache lines), which leaves LDS to the program and lets 16 waves share a CU.
+inline size_t pool_lds_bytes(uint32_t n_prog, uint32_t n_mat, uint32_t waves, bool stage_program, bool slots_in_lds) {
   size_t b = stage_program ? ((size_t)n_prog * 32 + (size_t)n_mat * 32) : 0;
-  b += (size_t)waves * POOL * POOL_FIELDS * 4;  // slots
-  b += (size_t)waves * POOL * 2 * 4;            // T-list + S-list
+  if (slots_in_lds) b += (size_t)waves * POOL * POOL_FIELDS * 4;  // slots
+  b += (size_t)waves * POOL * 2 * 4;                              // T-list + S-list
   return b;
 }
 
-template <bool USE_LDS, bool COUNT>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+RT_DEV uint4 fetch_hi_global(const DevScene& sc, uint32_t idx) {  // byte-offset skip pointers, global-memory variant
+  uint4 h = sc.hi[idx];
+  if ((h.w & 0xffu) == OP_BOX) h.z *= 32u;
+  return h;
+}
+
+template <bool USE_LDS, bool SLOTS_LDS, bool COUNT>
 __global__ __launch_bounds__(512) void render_lean_pool(DevScene sc, DevCamera cam, DevParams P,
                                                         float* __restrict__ out, uint32_t total_work,
                                                         uint32_t* __restrict__ queue, unsigned long long* counters,
-                                                        PoolTuning tune, ChunkMode cm) {
+                                                        PoolTuning tune, ChunkMode cm, uint32_t* __restrict__ g_slots) {
   extern __shared__ uint4 s_mem[];
   const uint32_t n_prog = sc.n_prog;
   const uint32_t staged = USE_LDS ? 2u * n_prog + 2u * sc.n_mat : 0u;  // uint4 units
+  // Program counters are BYTE offsets into the staged program: record r lives at [32 r, 32 r + 32) as
+  // (lo, hi), so a step needs no address arithmetic (ds_read_b128 pc / pc offset:16) and BOX skip
+  // pointers are stored pre-multiplied.
   if (USE_LDS) {
     for (uint32_t i = threadIdx.x; i < n_prog; i += blockDim.x) {
-      s_mem[i] = sc.lo[i];
-      s_mem[n_prog + i] = sc.hi[i];
+      uint4 h = sc.hi[i];
+      if ((h.w & 0xffu) == OP_BOX) h.z *= 32u;
+      s_mem[2u * i] = sc.lo[i];
+      s_mem[2u * i + 1u] = h;
     }
     for (uint32_t i = threadIdx.x; i < 2u * sc.n_mat; i += blockDim.x) s_mem[2u * n_prog + i] = sc.mat[i];
   }
-#define RT_FETCH_LO(pc_) (USE_LDS ? s_mem[(pc_)] : sc.lo[(pc_)])
-#define RT_FETCH_HI(pc_) (USE_LDS ? s_mem[n_prog + (pc_)] : sc.hi[(pc_)])
+  const char* s_bytes = reinterpret_cast<const char*>(s_mem);
+#define RT_FETCH_LO(pc_) (USE_LDS ? *reinterpret_cast<const uint4*>(s_bytes + (pc_)) : sc.lo[(pc_) >> 5])
+#define RT_FETCH_HI(pc_) (USE_LDS ? *reinterpret_cast<const uint4*>(s_bytes + (pc_) + 16u) : fetch_hi_global(sc, (pc_) >> 5))
 #define RT_FETCH_MAT(i_) (USE_LDS ? s_mem[2u * n_prog + (i_)] : sc.mat[(i_)])
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, n_waves = blockDim.x >> 6;
   uint32_t* pool_base = reinterpret_cast<uint32_t*>(s_mem + staged);
-  uint32_t* slot = pool_base + wave * (POOL * POOL_FIELDS);
+  uint32_t* slot = SLOTS_LDS ? pool_base + wave * (POOL * POOL_FIELDS)
+                             : g_slots + ((size_t)blockIdx.x * n_waves + wave) * (POOL * POOL_FIELDS);
   float* slotf = reinterpret_cast<float*>(slot);
-  uint32_t* tlist = pool_base + n_waves * (POOL * POOL_FIELDS) + wave * (2u * POOL);
+  uint32_t* tlist = pool_base + (SLOTS_LDS ? n_waves * (POOL * POOL_FIELDS) : 0u) + wave * (2u * POOL);
   uint32_t* slist = tlist + POOL;
 #define SLOT_U(f_, j_) slot[(f_)*POOL + (j_)]
 #define SLOT_F(f_, j_) slotf[(f_)*POOL + (j_)]
@@ -121,6 +139,8 @@ __global__ __launch_bounds__(512) void render_lean_pool(DevScene sc, DevCamera c
   const uint64_t seed = ((uint64_t)P.seed_hi << 32) | P.seed_lo;
   const float t_near = P.t_near;
   uint32_t t_count = 0, s_count = POOL, n_dead = 0;  // wave-uniform list sizes / retired slots
+  uint32_t w_next = 0, w_end = 0;                    // this wave's reserved range of work items
+  bool exhausted = false;                            // the global counter ran past total_work
 
   // ---- per-lane traversal state ---------------------------------------------------------------
   uint32_t my_slot = 0;
@@ -132,6 +152,7 @@ __global__ __launch_bounds__(512) void render_lean_pool(DevScene sc, DevCamera c
   Counts cnt = {0, 0, 0, 0};
   uint32_t total_draws = 0;
   uint32_t n_box_it = 0, n_box_lanes = 0, n_sph_it = 0, n_sph_lanes = 0, n_shade = 0, n_shade_lanes = 0, n_refill = 0;
+  unsigned long long t_shade = 0, t_serv = 0, t_box = 0, t_sph = 0, t_mark = 0, t_mark2 = 0;  // COUNT: s_memtime shares
 
   for (;;) {
     uint32_t op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
@@ -140,6 +161,7 @@ __global__ __launch_bounds__(512) void render_lean_pool(DevScene sc, DevCamera c
     const uint32_t n_busy = (uint32_t)__builtin_popcountll(m_box | m_sph);
     // ============================== SERVICE ======================================================
     if (64u - n_busy >= tune.refill_min || n_busy == 0) {
+      if (COUNT) t_mark = RT_TICK();
       // (1) finish: rays that reached END hand their result to their slot and join the S-list
       {
         const bool fin = have_ray && op == OP_END;
@@ -157,7 +179,7 @@ __global__ __launch_bounds__(512) void render_lean_pool(DevScene sc, DevCamera c
       while (s_count >= 64u || (s_count > 0 && t_count == 0 && n_busy == 0)) {
         const uint32_t take = s_count < 64u ? s_count : 64u;
         s_count -= take;
-        if (COUNT) n_shade++, n_shade_lanes += take;
+        if (COUNT) n_shade++, n_shade_lanes += take, t_mark2 = RT_TICK();
         uint32_t st = ST_DEAD, j = 0;
         V3 so = mk(0.f, 0.f, 0.f), sd = so, strength = so, accum = so, col = so;
         uint32_t bounces = 0, s = 0, x = 0, row = 0;
@@ -273,19 +295,28 @@ __global__ __launch_bounds__(512) void render_lean_pool(DevScene sc, DevCamera c
             }
           }
         }
-        // next pixel from the global work counter (one atomic per wave per round)
+        // next work item.  The wave reserves WORK_BLOCK items at a time from the global counter (one
+        // returning atomic per ~WORK_BLOCK samples: a single counter word saturates near 88 dequeues/us on
+        // this chip, which one-atomic-per-shade-pass reached) and hands them out to its lanes locally.
         for (;;) {
-          uint64_t need = __builtin_amdgcn_ballot_w64(st == ST_NEED_PIXEL);
+          const uint64_t need = __builtin_amdgcn_ballot_w64(st == ST_NEED_PIXEL);
           if (need == 0) break;
-          uint32_t base = 0;
-          if (lane == (uint32_t)__builtin_ctzll(need)) base = atomicAdd(queue, (uint32_t)__builtin_popcountll(need));
-          base = __builtin_amdgcn_readlane(base, __builtin_ctzll(need));
-          if (st == ST_NEED_PIXEL) {
-            uint32_t w = base + lane_rank(need);
-            if (w >= total_work) {
-              st = ST_DEAD;
+          if (w_next == w_end && !exhausted) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(queue, WORK_BLOCK);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= total_work) {
+              exhausted = true;
             } else {
-              uint32_t first = 0;
+              w_next = base;
+              w_end = (total_work - base < WORK_BLOCK) ? total_work : base + WORK_BLOCK;
+            }
+          }
+          const uint32_t avail = w_end - w_next;
+          if (st == ST_NEED_PIXEL) {
+            const uint32_t r = lane_rank(need);
+            if (r < avail) {
+              uint32_t w = w_next + r, first = 0;
               if (cm.scratch) {  // work item = (chunk, pixel), pixel-minor so a wave's grab stays coherent
                 const uint32_t c = w / cm.pix_work;
                 w -= c * cm.pix_work;
@@ -296,8 +327,12 @@ __global__ __launch_bounds__(512) void render_lean_pool(DevScene sc, DevCamera c
                 col = mk(0.f, 0.f, 0.f);
                 st = ST_GEN;
               }
+            } else if (exhausted) {
+              st = ST_DEAD;
             }
           }
+          const uint32_t n_need = (uint32_t)__builtin_popcountll(need);
+          w_next += n_need < avail ? n_need : avail;
         }
         if (st == ST_GEN) {  // par_cast closure, lib.rs:366-371 (event 0)
           const uint32_t y = P.ny - 1u - row;
@@ -328,6 +363,7 @@ __global__ __launch_bounds__(512) void render_lean_pool(DevScene sc, DevCamera c
         t_count += (uint32_t)__builtin_popcountll(m_live);
         n_dead += take - (uint32_t)__builtin_popcountll(m_live);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (COUNT) t_shade += RT_TICK() - t_mark2;
       }
       // (3) refill idle lanes from the T-list
       {
@@ -349,6 +385,7 @@ __global__ __launch_bounds__(512) void render_lean_pool(DevScene sc, DevCamera c
           if (COUNT) n_refill++;
         }
       }
+      if (COUNT) t_serv += RT_TICK() - t_mark;
       if (n_dead == POOL) break;  // every slot retired: this wave is done
       if (__builtin_amdgcn_ballot_w64(have_ray) == 0) continue;  // nothing to traverse yet: service again
       op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
@@ -361,27 +398,31 @@ __global__ __launch_bounds__(512) void render_lean_pool(DevScene sc, DevCamera c
       const uint32_t n0 = (uint32_t)__builtin_popcountll(b_box);
       const uint32_t floor_lanes = n0 > tune.box_leave ? n0 - tune.box_leave : 0u;
       uint32_t n_now;
+      if (COUNT) t_mark = RT_TICK();
+      const bool neg_x = inv.x < 0.f, neg_y = inv.y < 0.f, neg_z = inv.z < 0.f;  // aabb.rs:20-23
       do {
         if (COUNT) n_box_it++;
         if (op == OP_BOX) {  // Aabb::hit, aabb.rs:16-27
           if (COUNT) cnt.aabb++;
-          float t0x = (u2f(cur_lo.x) - o.x) * inv.x, t1x = (u2f(cur_lo.w) - o.x) * inv.x;
-          float t0y = (u2f(cur_lo.y) - o.y) * inv.y, t1y = (u2f(cur_hi.x) - o.y) * inv.y;
-          float t0z = (u2f(cur_lo.z) - o.z) * inv.z, t1z = (u2f(cur_hi.y) - o.z) * inv.z;
-          float ax = inv.x < 0.f ? t1x : t0x, bx = inv.x < 0.f ? t0x : t1x;
-          float ay = inv.y < 0.f ? t1y : t0y, by = inv.y < 0.f ? t0y : t1y;
-          float az = inv.z < 0.f ? t1z : t0z, bz = inv.z < 0.f ? t0z : t1z;
+          // per axis (t0, t1) = ((min, max) - o) * inv as one packed subtract + one packed multiply
+          const f32x2 tx = (f32x2{u2f(cur_lo.x), u2f(cur_lo.y)} - f32x2{o.x, o.x}) * f32x2{inv.x, inv.x};
+          const f32x2 ty = (f32x2{u2f(cur_lo.z), u2f(cur_lo.w)} - f32x2{o.y, o.y}) * f32x2{inv.y, inv.y};
+          const f32x2 tz = (f32x2{u2f(cur_hi.x), u2f(cur_hi.y)} - f32x2{o.z, o.z}) * f32x2{inv.z, inv.z};
+          float ax = neg_x ? tx.y : tx.x, bx = neg_x ? tx.x : tx.y;
+          float ay = neg_y ? ty.y : ty.x, by = neg_y ? ty.x : ty.y;
+          float az = neg_z ? tz.y : tz.x, bz = neg_z ? tz.x : tz.y;
           float start = rs_max(t_near, rs_max(rs_max(ax, ay), az));
           float end = rs_min(best, rs_min(rs_min(bx, by), bz));
-          pc = (end > start) ? pc + 1u : cur_hi.z;
+          pc = (end > start) ? pc + 32u : cur_hi.z;
           cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc);
           op = cur_hi.w & 0xffu;
         }
         n_now = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op == OP_BOX));
         if (COUNT) n_box_lanes += n_now;
       } while (n_now > floor_lanes);
+      if (COUNT) t_box += RT_TICK() - t_mark;
     } else if (b_sph != 0) {
-      if (COUNT) n_sph_it++, n_sph_lanes += (uint32_t)__builtin_popcountll(b_sph);
+      if (COUNT) n_sph_it++, n_sph_lanes += (uint32_t)__builtin_popcountll(b_sph), t_mark = RT_TICK();
       if (op == OP_SPHERE) {  // Sphere::hit, object.rs:84-111 (+ Translate :275)
         if (COUNT) cnt.prim++;
         V3 lo_o = o;
@@ -391,9 +432,10 @@ __global__ __launch_bounds__(512) void render_lean_pool(DevScene sc, DevCamera c
           best = t;
           best_pc = pc;
         }
-        pc++;
+        pc += 32u;
         cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc);
       }
+      if (COUNT) t_sph += RT_TICK() - t_mark;
     }
   }
   if (COUNT) {
@@ -408,6 +450,8 @@ __global__ __launch_bounds__(512) void render_lean_pool(DevScene sc, DevCamera c
       atomicAdd(&sched[2], (unsigned long long)n_sph_it), atomicAdd(&sched[3], (unsigned long long)n_sph_lanes);
       atomicAdd(&sched[4], (unsigned long long)n_shade), atomicAdd(&sched[5], (unsigned long long)n_shade_lanes);
       atomicAdd(&sched[6], (unsigned long long)n_refill);
+      atomicAdd(&counters[16], t_shade), atomicAdd(&counters[17], t_serv - t_shade), atomicAdd(&counters[18], t_box),
+          atomicAdd(&counters[19], t_sph);
     }
   }
 #undef RT_FETCH_LO

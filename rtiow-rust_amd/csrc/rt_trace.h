@@ -114,9 +114,9 @@ RT_DEV bool hit_top(const DevScene& sc, V3 o, V3 d, float time, float t_near, Sa
     if (op == OP_BOX) {  // Aabb::hit, aabb.rs:16-27
       if (COUNT) cnt.aabb++;
       if ((FEAT & FEAT_MEDIUM) && (hi.w & F_BVH_ROOT)) root_hits = nhits;
-      float t0x = (u2f(lo.x) - o.x) * inv.x, t1x = (u2f(lo.w) - o.x) * inv.x;
-      float t0y = (u2f(lo.y) - o.y) * inv.y, t1y = (u2f(hi.x) - o.y) * inv.y;
-      float t0z = (u2f(lo.z) - o.z) * inv.z, t1z = (u2f(hi.y) - o.z) * inv.z;
+      float t0x = (u2f(lo.x) - o.x) * inv.x, t1x = (u2f(lo.y) - o.x) * inv.x;
+      float t0y = (u2f(lo.z) - o.y) * inv.y, t1y = (u2f(lo.w) - o.y) * inv.y;
+      float t0z = (u2f(hi.x) - o.z) * inv.z, t1z = (u2f(hi.y) - o.z) * inv.z;
       float ax = inv.x < 0.f ? t1x : t0x, bx = inv.x < 0.f ? t0x : t1x;
       float ay = inv.y < 0.f ? t1y : t0y, by = inv.y < 0.f ? t0y : t1y;
       float az = inv.z < 0.f ? t1z : t0z, bz = inv.z < 0.f ? t0z : t1z;

@@ -146,6 +146,9 @@ struct rtg_scene {
   unsigned long long* d_counters = nullptr;  // [0..4] N/P/H/rays/draws, [7] = work-queue head (persistent kernel)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int num_cus = 0;
+  uint32_t* d_slots = nullptr;  // ray-pool path slots when they live in global memory
+  size_t slots_bytes = 0;
+  int slots_in_lds = 0;         // RTG_SLOTS_LDS=1: keep the path slots in LDS (8 waves/CU)
   float* d_scratch = nullptr;  // chunk-mode per-sample colours
   size_t scratch_bytes = 0;
   int force_chunks = 0;        // RTG_CHUNKS: 0 = automatic
@@ -213,6 +216,7 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
     if (n_chunks > 1 && need <= (16ull << 30) && pix_work * n_chunks <= 0xfffffffeull) {
       if (need > s->scratch_bytes) {
         if (s->d_scratch) (void)hipFree(s->d_scratch);
+  if (s->d_slots) (void)hipFree(s->d_slots);
         s->d_scratch = nullptr, s->scratch_bytes = 0;
         hipError_t ea = hipMalloc((void**)&s->d_scratch, need);
         if (ea != hipSuccess) return ea;
@@ -229,9 +233,13 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
   hipError_t e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream);  // re-initialise every call
   if (e != hipSuccess) return e;
   const size_t lds_limit = 160 * 1024;
-  bool use_lds = pool_lds_bytes(s->n_prog, s->n_mat, waves, true) <= lds_limit;
-  size_t lds = pool_lds_bytes(s->n_prog, s->n_mat, waves, use_lds);
-  auto kernel = use_lds ? render_lean_pool<true, COUNT> : render_lean_pool<false, COUNT>;
+  const bool slots_lds = s->slots_in_lds != 0;
+  bool use_lds = pool_lds_bytes(s->n_prog, s->n_mat, waves, true, slots_lds) <= lds_limit;
+  size_t lds = pool_lds_bytes(s->n_prog, s->n_mat, waves, use_lds, slots_lds);
+  void (*kernel)(DevScene, DevCamera, DevParams, float*, uint32_t, uint32_t*, unsigned long long*, PoolTuning, ChunkMode,
+                 uint32_t*);
+  if (slots_lds) kernel = use_lds ? render_lean_pool<true, true, COUNT> : render_lean_pool<false, true, COUNT>;
+  else kernel = use_lds ? render_lean_pool<true, false, COUNT> : render_lean_pool<false, false, COUNT>;
   e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   int per_cu = s->wg_per_cu;
@@ -246,8 +254,18 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
   if (getenv("RTG_VERBOSE"))
     fprintf(stderr, "[rtg] pool: grid %u x %d threads, %d WG/CU, lds %zu B (program staged: %d), %u chunk(s) of %u samples\n", grid,
             bt, per_cu, lds, (int)use_lds, cm.n_chunks, cm.chunk);
+  if (!slots_lds) {
+    size_t need = (size_t)grid * waves * POOL * POOL_FIELDS * sizeof(uint32_t);
+    if (need > s->slots_bytes) {
+      if (s->d_slots) (void)hipFree(s->d_slots);
+      s->d_slots = nullptr, s->slots_bytes = 0;
+      e = hipMalloc((void**)&s->d_slots, need);
+      if (e != hipSuccess) return e;
+      s->slots_bytes = need;
+    }
+  }
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(bt), lds, stream, s->dev, cam, d, d_out, (uint32_t)total_work, queue,
-                     s->d_counters, s->pool_tune, cm);
+                     s->d_counters, s->pool_tune, cm, s->d_slots);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (cm.scratch) {
@@ -531,6 +549,7 @@ void rtg_scene_destroy(rtg_scene* s) {
     if (p) (void)hipFree(p);
   if (s->d_counters) (void)hipFree(s->d_counters);
   if (s->d_scratch) (void)hipFree(s->d_scratch);
+  if (s->d_slots) (void)hipFree(s->d_slots);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   delete s;
@@ -578,6 +597,7 @@ int rtg_scene_create(rtg_builder* b, const rtg_id* world, size_t n, int device, 
   if (s->num_cus <= 0) s->num_cus = 256;
   if (const char* kv = getenv("RTG_KERNEL")) s->kernel_version = atoi(kv);  // A/B switches for measurements
   if (const char* kv = getenv("RTG_CHUNKS")) s->force_chunks = atoi(kv);
+  if (const char* kv = getenv("RTG_SLOTS_LDS")) s->slots_in_lds = atoi(kv);
   if (const char* kv = getenv("RTG_BLOCK")) s->block_threads = atoi(kv);
   if (const char* kv = getenv("RTG_WG_PER_CU")) s->wg_per_cu = atoi(kv);
   if (const char* kv = getenv("RTG_REGEN_MIN")) s->tune.regen_min = (uint32_t)atoi(kv);
@@ -680,8 +700,8 @@ int rtg_par_cast_device(rtg_scene* s, const rtg_camera* camera, const rtg_params
       unsigned long long q[16];
       HIP_TRY(hipMemcpy(q, s->d_counters + 8, sizeof(q), hipMemcpyDeviceToHost));
       double tt = (double)(q[8] + q[9] + q[10] + q[11]);
-      fprintf(stderr, "[rtg] wave-time shares (s_memtime, instrumented variant): shade %.1f%% gen+pull %.1f%% box %.1f%% sphere %.1f%%; "
-              "per pass: shade+... %.0f, gen %.0f, box %.0f, sphere %.0f ticks\n", 100 * q[8] / tt, 100 * q[9] / tt, 100 * q[10] / tt,
+      fprintf(stderr, "[rtg] wave-time shares (s_memtime, instrumented variant): shade %.1f%% gen+pull|service %.1f%% box %.1f%% sphere %.1f%%; "
+              "per pass: shade %.0f, gen|service %.0f, box %.0f, sphere %.0f ticks\n", 100 * q[8] / tt, 100 * q[9] / tt, 100 * q[10] / tt,
               100 * q[11] / tt, q[4] ? (double)q[8] / q[4] : 0., q[4] ? (double)q[9] / q[4] : 0., q[0] ? (double)q[10] / q[0] : 0.,
               q[2] ? (double)q[11] / q[2] : 0.);
       if (s->kernel_version >= 3)

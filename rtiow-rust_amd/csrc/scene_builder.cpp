@@ -217,7 +217,7 @@ static bool fuse_primitive(const SceneBuilder& b, uint32_t id, FlatScene* out, b
 void SceneBuilder::emit_bvh(int32_t node_id, int depth, FlatScene* out) const {
   const HostBvhNode& n = bvh_nodes[node_id];
   size_t at = out->lo.size();
-  push(out, n.box.mn[0], n.box.mn[1], n.box.mn[2], n.box.mx[0], fbits(n.box.mx[1]), fbits(n.box.mx[2]), 0, OP_BOX);
+  push(out, n.box.mn[0], n.box.mx[0], n.box.mn[1], n.box.mx[1], fbits(n.box.mn[2]), fbits(n.box.mx[2]), 0, OP_BOX);
   if (n.leaf != kNone) {
     emit(n.leaf, true, false, depth, out);
   } else {
