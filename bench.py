@@ -170,7 +170,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "render_kernel", "kernel_ms_avg": avg_kernel_ms,
+                "kernel": "rtg::render_lean_pool (+ rtg::fold_samples_kernel, <1%): HIP events around both on the launch stream",
+                "kernel_ms_avg": avg_kernel_ms,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "counters_per_launch": {k: cst[k] for k in ("aabb_tests", "prim_tests", "shaded_hits", "rays", "draws")},
             },
