@@ -92,33 +92,41 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 RT_DEV uint4 fetch_hi_global(const DevScene& sc, uint32_t idx) {  // byte-offset skip pointers, global-memory variant
   uint4 h = sc.hi[idx];
-  if ((h.w & 0xffu) == OP_BOX) h.z *= 32u;
+  if ((h.w & 0xffu) == OP_BOX) h.z *= 16u;
   return h;
 }
 
+#ifndef RT_POOL_MAX_THREADS
+#define RT_POOL_MAX_THREADS 512
+#endif
+#ifndef RT_POOL_WAVES_PER_EU
+#define RT_POOL_WAVES_PER_EU 1
+#endif
 template <bool USE_LDS, bool SLOTS_LDS, bool COUNT>
-__global__ __launch_bounds__(512) void render_lean_pool(DevScene sc, DevCamera cam, DevParams P,
+__global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void render_lean_pool(DevScene sc, DevCamera cam, DevParams P,
                                                         float* __restrict__ out, uint32_t total_work,
                                                         uint32_t* __restrict__ queue, unsigned long long* counters,
                                                         PoolTuning tune, ChunkMode cm, uint32_t* __restrict__ g_slots) {
   extern __shared__ uint4 s_mem[];
   const uint32_t n_prog = sc.n_prog;
   const uint32_t staged = USE_LDS ? 2u * n_prog + 2u * sc.n_mat : 0u;  // uint4 units
-  // Program counters are BYTE offsets into the staged program: record r lives at [32 r, 32 r + 32) as
-  // (lo, hi), so a step needs no address arithmetic (ds_read_b128 pc / pc offset:16) and BOX skip
-  // pointers are stored pre-multiplied.
+  // Program counters are BYTE offsets (16 r) into the staged lo[] array; hi[] follows at +16 n.  A step
+  // needs no shift (ds_read_b128 pc ; ds_read_b128 pc + hi_off) and BOX skip pointers are stored
+  // pre-multiplied.  SoA (not 32-byte AoS records) on purpose: a b128 gather of 16-byte packets then
+  // spreads over all 64 LDS banks, an AoS layout would use only every other 4-bank group per load.
+  const uint32_t hi_off = 16u * n_prog;
   if (USE_LDS) {
     for (uint32_t i = threadIdx.x; i < n_prog; i += blockDim.x) {
       uint4 h = sc.hi[i];
-      if ((h.w & 0xffu) == OP_BOX) h.z *= 32u;
-      s_mem[2u * i] = sc.lo[i];
-      s_mem[2u * i + 1u] = h;
+      if ((h.w & 0xffu) == OP_BOX) h.z *= 16u;
+      s_mem[i] = sc.lo[i];
+      s_mem[n_prog + i] = h;
     }
     for (uint32_t i = threadIdx.x; i < 2u * sc.n_mat; i += blockDim.x) s_mem[2u * n_prog + i] = sc.mat[i];
   }
   const char* s_bytes = reinterpret_cast<const char*>(s_mem);
-#define RT_FETCH_LO(pc_) (USE_LDS ? *reinterpret_cast<const uint4*>(s_bytes + (pc_)) : sc.lo[(pc_) >> 5])
-#define RT_FETCH_HI(pc_) (USE_LDS ? *reinterpret_cast<const uint4*>(s_bytes + (pc_) + 16u) : fetch_hi_global(sc, (pc_) >> 5))
+#define RT_FETCH_LO(pc_) (USE_LDS ? *reinterpret_cast<const uint4*>(s_bytes + (pc_)) : sc.lo[(pc_) >> 4])
+#define RT_FETCH_HI(pc_) (USE_LDS ? *reinterpret_cast<const uint4*>(s_bytes + hi_off + (pc_)) : fetch_hi_global(sc, (pc_) >> 4))
 #define RT_FETCH_MAT(i_) (USE_LDS ? s_mem[2u * n_prog + (i_)] : sc.mat[(i_)])
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, n_waves = blockDim.x >> 6;
   uint32_t* pool_base = reinterpret_cast<uint32_t*>(s_mem + staged);
@@ -413,7 +421,7 @@ __global__ __launch_bounds__(512) void render_lean_pool(DevScene sc, DevCamera c
           float az = neg_z ? tz.y : tz.x, bz = neg_z ? tz.x : tz.y;
           float start = rs_max(t_near, rs_max(rs_max(ax, ay), az));
           float end = rs_min(best, rs_min(rs_min(bx, by), bz));
-          pc = (end > start) ? pc + 32u : cur_hi.z;
+          pc = (end > start) ? pc + 16u : cur_hi.z;
           cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc);
           op = cur_hi.w & 0xffu;
         }
@@ -432,7 +440,7 @@ __global__ __launch_bounds__(512) void render_lean_pool(DevScene sc, DevCamera c
           best = t;
           best_pc = pc;
         }
-        pc += 32u;
+        pc += 16u;
         cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc);
       }
       if (COUNT) t_sph += RT_TICK() - t_mark;

@@ -216,7 +216,6 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
     if (n_chunks > 1 && need <= (16ull << 30) && pix_work * n_chunks <= 0xfffffffeull) {
       if (need > s->scratch_bytes) {
         if (s->d_scratch) (void)hipFree(s->d_scratch);
-  if (s->d_slots) (void)hipFree(s->d_slots);
         s->d_scratch = nullptr, s->scratch_bytes = 0;
         hipError_t ea = hipMalloc((void**)&s->d_scratch, need);
         if (ea != hipSuccess) return ea;

@@ -235,3 +235,13 @@ def test_every_kernel_variant_and_schedule_gives_the_same_bits(pkg, gpu, oracle,
             assert st_g[k] == st_o[k], (name, env, k)
         assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns, rank=1, nranks=3), so.par_cast(cam_o, nx, ny, ns, rank=1, nranks=3),
                          "%s shard %s" % (name, env))
+
+
+def test_scene_reuse_across_sizes_and_sample_counts(pkg, gpu, oracle):
+    """One scene handle, many calls: the library's scratch / path-slot buffers are grown lazily (a
+    use-after-free here once produced a GPU memory fault when a second call needed a bigger scratch)."""
+    sg, cam_g, _, _, _ = build_case(pkg, gpu, "book1", 96, 64)
+    so, cam_o, _, _, _ = build_case(pkg, oracle, "book1", 96, 64)
+    for (nx, ny, ns) in [(64, 64, 1), (64, 64, 2), (96, 64, 1), (96, 64, 9), (32, 16, 40), (96, 64, 3)]:
+        cg = gpu.camera_look(pkg.scenes.v(13, 2, 3), pkg.scenes.v(0, 0, 0), pkg.scenes.v(0, 1, 0), 20.0, nx / ny, 0.1, 10.0)
+        assert_bit_equal(sg.par_cast(cg, nx, ny, ns), so.par_cast(cg, nx, ny, ns), "%dx%dx%d" % (nx, ny, ns))
