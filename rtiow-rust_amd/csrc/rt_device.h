@@ -88,7 +88,7 @@ RT_DEV float rt_pow5f(float x) {
 }
 
 // f32::sin of the checker texture (texture.rs:14): f64 Cody-Waite + Taylor kernels.
-RT_DEV float rt_sinf(float x) {
+__device__ __attribute__((noinline)) float rt_sinf(float x) {  // rare (checker texture): kept out of line
   if (!(__builtin_fabsf(x) <= 3.0e38f)) return __builtin_nanf("");
   double y = (double)x;
   double n = __builtin_rint(y * 0x1.45f306dc9c883p-1);
@@ -166,6 +166,20 @@ struct SampleRng {
     b0 = c0, b1 = c1, b2 = c2, b3 = c3;
     blk++;
     left = 4;
+  }
+  // continue the current event's stream after `k` words were already consumed elsewhere (the medium
+  // draws of this event's traversal); does not count as draws of this generator
+  RT_DEV void seek(uint32_t k) {
+    blk = k >> 2;
+    left = 0;
+    const uint32_t skip = k & 3u;
+    if (skip) {
+      refill();
+      if (skip >= 1u) b0 = b1, b1 = b2, b2 = b3;
+      if (skip >= 2u) b0 = b1, b1 = b2;
+      if (skip >= 3u) b0 = b1;
+      left = 4u - skip;
+    }
   }
   RT_DEV uint32_t next_u32() {
     if (left == 0) refill();

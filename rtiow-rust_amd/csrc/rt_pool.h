@@ -90,6 +90,8 @@ inline size_t pool_lds_bytes(uint32_t n_prog, uint32_t n_mat, uint32_t waves, bo
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+RT_DEV bool hi_is_root(uint4 hi) { return (hi.w & F_BVH_ROOT) != 0u; }
+
 RT_DEV uint4 fetch_hi_global(const DevScene& sc, uint32_t idx) {  // byte-offset skip pointers, global-memory variant
   uint4 h = sc.hi[idx];
   if ((h.w & 0xffu) == OP_BOX) h.z *= 16u;

@@ -1,0 +1,464 @@
+// rt_pool_full.h -- the ray-pool schedule of rt_pool.h for EVERY feature of the hot path: Rect,
+// PUSH/POP transform wrappers (Translate / RotateY / Scale / LinearMove / FlipNormals over subtrees),
+// ConstantMedium (RNG draws during traversal), checker / Perlin textures, Isotropic.
+//
+// Differences from the lean kernel:
+//  * the hit record (p, normal, material) is built at hit time and carried in registers, because it
+//    has to travel back through the enclosing POPs (object.rs:279-282,365-369); at END it is written
+//    to the path slot (7 dwords) instead of (best, best_pc);
+//  * every non-BOX record (SPHERE, RECT, PUSH, POP, MEDIUM) is a "slow op": lanes park on it and a slow
+//    pass executes one record per parked lane once enough lanes wait (or no BOX lane is left);
+//  * the transform stack (<= 4 saved rays) lives in a per-wave, lane-interleaved global scratch;
+//  * a medium draws from the event's RNG stream by index (event_draw), and the number of draws made
+//    during traversal travels with the path so that Material::scatter continues the stream where
+//    traversal left it (draw order of SURVEY 8a);
+//  * always one sample per work item + ordered fold (the host falls back to render_kernel when the
+//    sample scratch would not fit).
+#pragma once
+#include "rt_pool.h"
+
+namespace rtg {
+
+constexpr uint32_t FPOOL_FIELDS = 24;
+enum FullPoolField : uint32_t {
+  FF_O = 0, FF_D = 3, FF_TIME = 6, FF_HITMAT = 7, FF_P = 8, FF_N = 11, FF_STRENGTH = 14, FF_ACCUM = 17, FF_BOUNCES = 20,
+  FF_SAMPLE = 21, FF_XY = 22, FF_EVDRAWS = 23,
+};
+
+inline size_t full_pool_lds_bytes(uint32_t n_prog, uint32_t waves, bool stage_program) {
+  return (stage_program ? (size_t)n_prog * 32 : 0) + (size_t)waves * POOL * 2 * 4;
+}
+
+// draw `idx` (0-based) of the stream (seed, pixel, sample, event): word idx%4 of Philox block idx/4
+__device__ __attribute__((noinline)) float event_draw_f32(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t event, uint32_t idx) {
+#ifdef RT_STUB_EVD
+  return 0.5f;
+#endif
+  SampleRng r;
+  r.init(seed, pixel, sample);
+  r.set_event(event);
+  r.blk = idx >> 2;
+  r.refill();
+  uint32_t w = idx & 3u;
+  uint32_t u = w == 0 ? r.b0 : (w == 1 ? r.b1 : (w == 2 ? r.b2 : r.b3));
+  return (float)(u >> 8) * (1.0f / 16777216.0f);
+}
+
+template <bool USE_LDS, bool TEX, bool COUNT>
+__global__ __launch_bounds__(512) void render_full_pool(DevScene sc, DevCamera cam, DevParams P, float* __restrict__ out,
+                                                        uint32_t total_work, uint32_t* __restrict__ queue,
+                                                        unsigned long long* counters, PoolTuning tune, ChunkMode cm,
+                                                        uint32_t* __restrict__ g_slots, float* __restrict__ g_stack) {
+  // TEX = the scene references a checker / Perlin texture: only then is texture_eval (and its register
+  // footprint) compiled in
+  constexpr uint32_t FEAT = FEAT_XFORM | FEAT_MEDIUM | FEAT_RECT | (TEX ? FEAT_TEXTURE : 0u);
+  extern __shared__ uint4 s_mem[];
+  const uint32_t n_prog = sc.n_prog;
+  const uint32_t staged = USE_LDS ? 2u * n_prog : 0u;  // uint4 units
+  const uint32_t hi_off = 16u * n_prog;
+  if (USE_LDS) {
+    for (uint32_t i = threadIdx.x; i < n_prog; i += blockDim.x) {
+      uint4 h = sc.hi[i];
+      if ((h.w & 0xffu) == OP_BOX) h.z *= 16u;
+      s_mem[i] = sc.lo[i];
+      s_mem[n_prog + i] = h;
+    }
+  }
+  const char* s_bytes = reinterpret_cast<const char*>(s_mem);
+#define RT_FETCH_LO(pc_) (USE_LDS ? *reinterpret_cast<const uint4*>(s_bytes + (pc_)) : sc.lo[(pc_) >> 4])
+#define RT_FETCH_HI(pc_) (USE_LDS ? *reinterpret_cast<const uint4*>(s_bytes + hi_off + (pc_)) : fetch_hi_global(sc, (pc_) >> 4))
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, n_waves = blockDim.x >> 6;
+  const size_t gwave = (size_t)blockIdx.x * n_waves + wave;
+  uint32_t* slot = g_slots + gwave * (POOL * FPOOL_FIELDS);
+  float* slotf = reinterpret_cast<float*>(slot);
+  float* stack = g_stack + gwave * (MAX_XFORM_DEPTH * 6 * 64);  // [level][component][lane]
+  uint32_t* tlist = reinterpret_cast<uint32_t*>(s_mem + staged) + wave * (2u * POOL);
+  uint32_t* slist = tlist + POOL;
+#define SLOT_U(f_, j_) slot[(f_)*POOL + (j_)]
+#define SLOT_F(f_, j_) slotf[(f_)*POOL + (j_)]
+  for (uint32_t j = lane; j < POOL; j += 64u) {
+    SLOT_U(FF_HITMAT, j) = SLOT_NEED_PIXEL;
+    slist[j] = j;
+  }
+  __syncthreads();
+
+  const uint64_t seed = ((uint64_t)P.seed_hi << 32) | P.seed_lo;
+  const float t_near = P.t_near;
+  uint32_t t_count = 0, s_count = POOL, n_dead = 0;
+  uint32_t w_next = 0, w_end = 0;
+  bool exhausted = false;
+
+  // ---- per-lane traversal state ---------------------------------------------------------------
+  uint32_t my_slot = 0;
+  bool have_ray = false;
+  V3 o = mk(0.f, 0.f, 0.f), d = o, inv = o;
+  float time = 0.f, best = F32_MAX;
+  uint32_t pc = 0;
+  uint4 cur_lo = make_uint4(0, 0, 0, 0), cur_hi = make_uint4(0, 0, 0, OP_END);
+  V3 hp = o, hn = o;                 // hit record (object.rs:61-71), in the space of wrapper depth `tag`
+  uint32_t hmat = NO_HIT;            // NO_HIT = None
+  uint32_t depth = 0, tag = 0, nhits = 0, root_hits = 0, ev_draws = 0;
+  uint32_t r_pixel = 0, r_sample = 0, r_event = 0;  // RNG stream of this ray's event (media)
+  Counts cnt = {0, 0, 0, 0};
+  uint32_t total_draws = 0;
+  uint32_t n_box_it = 0, n_box_lanes = 0, n_slow_it = 0, n_slow_lanes = 0, n_shade = 0, n_shade_lanes = 0, n_refill = 0;
+
+  for (;;) {
+    uint32_t op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
+    const uint64_t m_box = __builtin_amdgcn_ballot_w64(op == OP_BOX);
+    const uint64_t m_slow = __builtin_amdgcn_ballot_w64(op >= OP_SPHERE && op <= OP_MEDIUM);
+    const uint32_t n_busy = (uint32_t)__builtin_popcountll(m_box | m_slow);
+    // ============================== SERVICE ======================================================
+    if (64u - n_busy >= tune.refill_min || n_busy == 0) {
+      {  // (1) finish
+        const bool fin = have_ray && op == OP_END;
+        const uint64_t m_fin = __builtin_amdgcn_ballot_w64(fin);
+        if (fin) {
+          SLOT_U(FF_HITMAT, my_slot) = hmat;
+          SLOT_F(FF_P, my_slot) = hp.x, SLOT_F(FF_P + 1, my_slot) = hp.y, SLOT_F(FF_P + 2, my_slot) = hp.z;
+          SLOT_F(FF_N, my_slot) = hn.x, SLOT_F(FF_N + 1, my_slot) = hn.y, SLOT_F(FF_N + 2, my_slot) = hn.z;
+          SLOT_U(FF_EVDRAWS, my_slot) = ev_draws;
+          slist[s_count + lane_rank(m_fin)] = my_slot;
+          have_ray = false;
+        }
+        s_count += (uint32_t)__builtin_popcountll(m_fin);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      // (2) shade
+      while (s_count >= 64u || (s_count > 0 && t_count == 0 && n_busy == 0)) {
+        const uint32_t take = s_count < 64u ? s_count : 64u;
+        s_count -= take;
+        if (COUNT) n_shade++, n_shade_lanes += take;
+        uint32_t st = ST_DEAD, j = 0;
+        V3 so = mk(0.f, 0.f, 0.f), sd = so, strength = so, accum = so;
+        float stime = 0.f;
+        uint32_t bounces = 0, s = 0, x = 0, row = 0;
+        if (lane < take) {
+          j = slist[s_count + lane];
+          const uint32_t hm = SLOT_U(FF_HITMAT, j);
+          if (hm == SLOT_NEED_PIXEL) {
+            st = ST_NEED_PIXEL;
+          } else {
+            so = mk(SLOT_F(FF_O, j), SLOT_F(FF_O + 1, j), SLOT_F(FF_O + 2, j));
+            sd = mk(SLOT_F(FF_D, j), SLOT_F(FF_D + 1, j), SLOT_F(FF_D + 2, j));
+            stime = SLOT_F(FF_TIME, j);
+            strength = mk(SLOT_F(FF_STRENGTH, j), SLOT_F(FF_STRENGTH + 1, j), SLOT_F(FF_STRENGTH + 2, j));
+            accum = mk(SLOT_F(FF_ACCUM, j), SLOT_F(FF_ACCUM + 1, j), SLOT_F(FF_ACCUM + 2, j));
+            bounces = SLOT_U(FF_BOUNCES, j), s = SLOT_U(FF_SAMPLE, j);
+            const uint32_t xy = SLOT_U(FF_XY, j);
+            x = xy & 0xffffu, row = xy >> 16;
+            // ---------------- color() loop body, lib.rs:73-97 ----------------
+            SampleRng rng;
+            rng.init(seed, (P.ny - 1u - row) * P.nx + x, s);
+            rng.set_event(bounces + 1u);
+            rng.seek(SLOT_U(FF_EVDRAWS, j));  // continue after the medium draws of this event's traversal
+            bool ended = true;
+            V3 result = mk(0.f, 0.f, 0.f);
+            if (hm != NO_HIT) {
+              if (COUNT) cnt.shaded++;
+              const V3 p = mk(SLOT_F(FF_P, j), SLOT_F(FF_P + 1, j), SLOT_F(FF_P + 2, j));
+              const V3 n = mk(SLOT_F(FF_N, j), SLOT_F(FF_N + 1, j), SLOT_F(FF_N + 2, j));
+              const uint4 mlo = sc.mat[2 * hm], mhi = sc.mat[2 * hm + 1];
+              const uint32_t kind = mhi.w & 0xffu;
+              const float param = u2f(mlo.w);
+              V3 emitted = mk(0.f, 0.f, 0.f);
+              if (kind == MAT_DIFFUSE_LIGHT) emitted = smul(param, material_texture<FEAT>(sc, mlo, mhi, p));
+              accum = vadd(accum, vmul(strength, emitted));
+              V3 nd = mk(0.f, 0.f, 0.f), att = mk(0.f, 0.f, 0.f);
+              bool scattered = true;
+              V3 rs = mk(0.f, 0.f, 0.f);
+              if (kind == MAT_LAMBERTIAN || kind == MAT_METAL || kind == MAT_ISOTROPIC) rs = in_unit_sphere(rng);
+              if (kind == MAT_LAMBERTIAN) {
+                V3 target = vadd(vadd(p, n), rs);
+                nd = vsub(target, p);
+                att = material_texture<FEAT>(sc, mlo, mhi, p);
+              } else if (kind == MAT_METAL) {
+                V3 refl = reflect(vunit(sd), n);
+                nd = vadd(refl, smul(param, rs));
+                att = mk(u2f(mlo.x), u2f(mlo.y), u2f(mlo.z));
+                scattered = vdot(nd, n) > 0.f;
+              } else if (kind == MAT_DIELECTRIC) {
+                V3 outward;
+                float ni_over_nt, cosine;
+                float dn = vdot(sd, n);
+                if (dn > 0.f) {
+                  outward = vneg(n);
+                  ni_over_nt = param;
+                  cosine = param * dn / vlen(sd);
+                } else {
+                  outward = n;
+                  ni_over_nt = 1.0f / param;
+                  cosine = -dn / vlen(sd);
+                }
+                V3 uv = vunit(sd);
+                float dt = vdot(uv, outward);
+                float disc = 1.0f - ni_over_nt * ni_over_nt * (1.f - dt * dt);
+                bool refracted = disc > 0.f;
+                if (refracted) {
+                  nd = vsub(smul(ni_over_nt, vsub(uv, smul(dt, outward))), smul(__builtin_sqrtf(disc), outward));
+                  refracted = rng.gen_f32() >= schlick(cosine, param);
+                }
+                if (!refracted) nd = reflect(sd, n);
+                att = splat(1.f);
+              } else if (kind == MAT_DIFFUSE_LIGHT) {
+                scattered = false;
+              } else {  // Isotropic
+                nd = rs;
+                att = material_texture<FEAT>(sc, mlo, mhi, p);
+              }
+              result = accum;
+              if (scattered) {
+                so = p, sd = nd;  // time is carried over by every material
+                strength = vmul(strength, att);
+                if (bounces != P.max_bounces) {
+                  bounces += 1;
+                  ended = false;
+                }
+              }
+            }
+            if (COUNT) total_draws += rng.draws;
+            if (ended) {
+              float* sp = cm.scratch + 3ull * ((size_t)s * cm.pix_work + pixel_to_work(P, x, row));
+              sp[0] = result.x, sp[1] = result.y, sp[2] = result.z;
+              s++;
+              st = (s == P.ns || s % cm.chunk == 0u) ? ST_NEED_PIXEL : ST_GEN;
+            } else {
+              st = ST_TRAV;
+            }
+          }
+        }
+        for (;;) {  // next work item (see rt_pool.h)
+          const uint64_t need = __builtin_amdgcn_ballot_w64(st == ST_NEED_PIXEL);
+          if (need == 0) break;
+          if (w_next == w_end && !exhausted) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(queue, WORK_BLOCK);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= total_work) {
+              exhausted = true;
+            } else {
+              w_next = base;
+              w_end = (total_work - base < WORK_BLOCK) ? total_work : base + WORK_BLOCK;
+            }
+          }
+          const uint32_t avail = w_end - w_next;
+          if (st == ST_NEED_PIXEL) {
+            const uint32_t r = lane_rank(need);
+            if (r < avail) {
+              uint32_t w = w_next + r;
+              const uint32_t c = w / cm.pix_work;
+              w -= c * cm.pix_work;
+              const uint32_t first = c * cm.chunk;
+              if (work_to_pixel(P, w, x, row) && first < P.ns) {
+                s = first;
+                st = ST_GEN;
+              }
+            } else if (exhausted) {
+              st = ST_DEAD;
+            }
+          }
+          const uint32_t n_need = (uint32_t)__builtin_popcountll(need);
+          w_next += n_need < avail ? n_need : avail;
+        }
+        if (st == ST_GEN) {  // par_cast closure, lib.rs:366-371 (event 0)
+          const uint32_t y = P.ny - 1u - row;
+          SampleRng rng;
+          rng.init(seed, y * P.nx + x, s);
+          float u = ((float)x + rng.gen_f32()) / (float)P.nx;
+          float v = ((float)y + rng.gen_f32()) / (float)P.ny;
+          get_ray(cam, u, v, rng, so, sd, stime);
+          accum = mk(0.f, 0.f, 0.f), strength = splat(1.f), bounces = 0;
+          if (COUNT) total_draws += rng.draws;
+          st = ST_TRAV;
+        }
+        const bool live = st == ST_TRAV;
+        const uint64_t m_live = __builtin_amdgcn_ballot_w64(live);
+        if (live) {
+          SLOT_F(FF_O, j) = so.x, SLOT_F(FF_O + 1, j) = so.y, SLOT_F(FF_O + 2, j) = so.z;
+          SLOT_F(FF_D, j) = sd.x, SLOT_F(FF_D + 1, j) = sd.y, SLOT_F(FF_D + 2, j) = sd.z;
+          SLOT_F(FF_TIME, j) = stime;
+          SLOT_F(FF_STRENGTH, j) = strength.x, SLOT_F(FF_STRENGTH + 1, j) = strength.y, SLOT_F(FF_STRENGTH + 2, j) = strength.z;
+          SLOT_F(FF_ACCUM, j) = accum.x, SLOT_F(FF_ACCUM + 1, j) = accum.y, SLOT_F(FF_ACCUM + 2, j) = accum.z;
+          SLOT_U(FF_BOUNCES, j) = bounces, SLOT_U(FF_SAMPLE, j) = s;
+          SLOT_U(FF_XY, j) = x | (row << 16);
+          tlist[t_count + lane_rank(m_live)] = j;
+          if (COUNT) cnt.rays++;
+        }
+        t_count += (uint32_t)__builtin_popcountll(m_live);
+        n_dead += take - (uint32_t)__builtin_popcountll(m_live);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      }
+      {  // (3) refill
+        const uint64_t m_idle = __builtin_amdgcn_ballot_w64(!have_ray);
+        const uint32_t n_idle = (uint32_t)__builtin_popcountll(m_idle);
+        const uint32_t got = n_idle < t_count ? n_idle : t_count;
+        if (got) {
+          const uint32_t r = lane_rank(m_idle);
+          if (!have_ray && r < got) {
+            my_slot = tlist[t_count - 1u - r];
+            o = mk(SLOT_F(FF_O, my_slot), SLOT_F(FF_O + 1, my_slot), SLOT_F(FF_O + 2, my_slot));
+            d = mk(SLOT_F(FF_D, my_slot), SLOT_F(FF_D + 1, my_slot), SLOT_F(FF_D + 2, my_slot));
+            time = SLOT_F(FF_TIME, my_slot);
+            const uint32_t xy = SLOT_U(FF_XY, my_slot);
+            r_pixel = (P.ny - 1u - (xy >> 16)) * P.nx + (xy & 0xffffu);
+            r_sample = SLOT_U(FF_SAMPLE, my_slot);
+            r_event = SLOT_U(FF_BOUNCES, my_slot) + 1u;
+            inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+            pc = 0, best = F32_MAX, hmat = NO_HIT;
+            depth = 0, tag = 0, nhits = 0, root_hits = 0, ev_draws = 0;
+            cur_lo = RT_FETCH_LO(0), cur_hi = RT_FETCH_HI(0);
+            have_ray = true;
+          }
+          t_count -= got;
+          if (COUNT) n_refill++;
+        }
+      }
+      if (n_dead == POOL) break;
+      if (__builtin_amdgcn_ballot_w64(have_ray) == 0) continue;
+      op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
+    }
+    // ============================== TRAVERSE ======================================================
+    const uint64_t b_box = __builtin_amdgcn_ballot_w64(op == OP_BOX);
+    const uint64_t b_slow = __builtin_amdgcn_ballot_w64(op >= OP_SPHERE && op <= OP_MEDIUM);
+    if (b_box != 0 && (uint32_t)__builtin_popcountll(b_slow) < tune.sphere_min) {
+      const uint32_t n0 = (uint32_t)__builtin_popcountll(b_box);
+      const uint32_t floor_lanes = n0 > tune.box_leave ? n0 - tune.box_leave : 0u;
+      uint32_t n_now;
+      do {
+        if (COUNT) n_box_it++;
+        if (op == OP_BOX) {  // Aabb::hit, aabb.rs:16-27 (1/d and its sign re-read: d changes under RotateY/Scale)
+          if (COUNT) cnt.aabb++;
+          if (hi_is_root(cur_hi)) root_hits = nhits;
+          const f32x2 tx = (f32x2{u2f(cur_lo.x), u2f(cur_lo.y)} - f32x2{o.x, o.x}) * f32x2{inv.x, inv.x};
+          const f32x2 ty = (f32x2{u2f(cur_lo.z), u2f(cur_lo.w)} - f32x2{o.y, o.y}) * f32x2{inv.y, inv.y};
+          const f32x2 tz = (f32x2{u2f(cur_hi.x), u2f(cur_hi.y)} - f32x2{o.z, o.z}) * f32x2{inv.z, inv.z};
+          float ax = inv.x < 0.f ? tx.y : tx.x, bx = inv.x < 0.f ? tx.x : tx.y;
+          float ay = inv.y < 0.f ? ty.y : ty.x, by = inv.y < 0.f ? ty.x : ty.y;
+          float az = inv.z < 0.f ? tz.y : tz.x, bz = inv.z < 0.f ? tz.x : tz.y;
+          float start = rs_max(t_near, rs_max(rs_max(ax, ay), az));
+          float end = rs_min(best, rs_min(rs_min(bx, by), bz));
+          pc = (end > start) ? pc + 16u : cur_hi.z;
+          cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc);
+          op = cur_hi.w & 0xffu;
+        }
+        n_now = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op == OP_BOX));
+        if (COUNT) n_box_lanes += n_now;
+      } while (n_now > floor_lanes);
+    } else if (b_slow != 0) {
+      // ---- slow pass: every parked lane executes ONE record ----
+      if (COUNT) n_slow_it++, n_slow_lanes += (uint32_t)__builtin_popcountll(b_slow);
+      if (op == OP_SPHERE) {  // Sphere::hit, object.rs:84-111 (+ fused Translate / FlipNormals)
+        if (COUNT) cnt.prim++;
+        const V3 off = mk(u2f(cur_lo.x), u2f(cur_lo.y), u2f(cur_lo.z));
+        V3 lo_o = o;
+        if (cur_hi.w & F_TRANSLATE) lo_o = vsub(o, off);
+        float t;
+        if (sphere_hit_t(lo_o, d, u2f(cur_lo.w), t_near, best, t)) {
+          V3 p = vadd(lo_o, smul(t, d));
+          V3 n = sdiv(p, u2f(cur_lo.w));
+          if (cur_hi.w & F_TRANSLATE) p = vadd(p, off);
+          if (cur_hi.w & F_FLIP) n = vneg(n);
+          hp = p, hn = n, hmat = cur_hi.z;
+          best = t, tag = depth, nhits++;
+        }
+        pc += 16u;
+      } else if (op == OP_RECT) {  // Rect::hit, object.rs:185-218
+        if (COUNT) cnt.prim++;
+        const uint32_t axis = (cur_hi.w >> F_AXIS_SHIFT) & 3u;
+        float t;
+        if (rect_hit_t(o, d, axis, u2f(cur_lo.x), u2f(cur_lo.y), u2f(cur_lo.z), u2f(cur_lo.w), u2f(cur_hi.x), t_near, best, t)) {
+          V3 n = mk(axis == 0 ? 1.f : 0.f, axis == 1 ? 1.f : 0.f, axis == 2 ? 1.f : 0.f);
+          if (cur_hi.w & F_FLIP) n = vneg(n);
+          hp = vadd(o, smul(t, d)), hn = n, hmat = cur_hi.z;
+          best = t, tag = depth, nhits++;
+        }
+        pc += 16u;
+      } else if (op == OP_PUSH) {
+        const uint32_t kind = (cur_hi.w >> F_KIND_SHIFT) & 7u;
+        float* sp = stack + depth * (6u * 64u) + lane;
+        sp[0] = o.x, sp[64] = o.y, sp[128] = o.z, sp[192] = d.x, sp[256] = d.y, sp[320] = d.z;
+        depth++;
+        const V3 a = mk(u2f(cur_lo.x), u2f(cur_lo.y), u2f(cur_lo.z));
+        if (kind == XF_TRANSLATE) {
+          o = vsub(o, a);
+        } else if (kind == XF_ROTATE_Y) {
+          o = rot_y(o, -a.x, a.y), d = rot_y(d, -a.x, a.y);
+          inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+        } else if (kind == XF_SCALE) {
+          o = vdiv(o, a), d = vdiv(d, a);
+          inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+        } else if (kind == XF_MOVE) {
+          o = vsub(o, smul(time, a));
+        }
+        pc += 16u;
+      } else if (op == OP_POP) {
+        const uint32_t kind = (cur_hi.w >> F_KIND_SHIFT) & 7u;
+        depth--;
+        if (hmat != NO_HIT && tag == depth + 1u) {
+          const V3 a = mk(u2f(cur_lo.x), u2f(cur_lo.y), u2f(cur_lo.z));
+          if (kind == XF_TRANSLATE) {
+            hp = vadd(hp, a);
+          } else if (kind == XF_ROTATE_Y) {
+            hp = rot_y(hp, a.x, a.y), hn = rot_y(hn, a.x, a.y);
+          } else if (kind == XF_SCALE) {
+            hp = vmul(hp, a), hn = vdiv(hn, a);
+          } else if (kind == XF_FLIP) {
+            hn = vneg(hn);
+          }
+          tag = depth;
+        }
+        const float* sp = stack + depth * (6u * 64u) + lane;
+        o = mk(sp[0], sp[64], sp[128]), d = mk(sp[192], sp[256], sp[320]);
+        if (kind == XF_ROTATE_Y || kind == XF_SCALE) inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+        pc += 16u;
+      } else if (op == OP_MEDIUM) {  // ConstantMedium::hit, object.rs:545-575
+        const uint4 blo = RT_FETCH_LO(pc + 16u), bhi = RT_FETCH_HI(pc + 16u);
+        float t1, t2;
+        if (COUNT) cnt.prim++;
+        if (prim_hit_t(blo, bhi, o, d, -F32_MAX, F32_MAX, t1)) {
+          if (COUNT) cnt.prim++;
+          if (prim_hit_t(blo, bhi, o, d, t1 + 0.0001f, F32_MAX, t2)) {
+            t1 = rs_max(t1, t_near);
+            t2 = rs_min(t2, best);
+            if (!(t1 >= t2)) {
+              float distance_inside = (t2 - t1) * vlen(d);
+              float hit_distance = -(1.f / u2f(cur_lo.x)) * rt_logf(event_draw_f32(seed, r_pixel, r_sample, r_event, ev_draws));
+              ev_draws++;
+              if (COUNT) total_draws++;
+              if (hit_distance < distance_inside) {
+                float t = t1 + hit_distance / vlen(d);
+                bool accept = !(cur_hi.w & F_UNDER_BVH) || nhits == root_hits || !(best < t);
+                if (accept) {
+                  hp = vadd(o, smul(t, d)), hn = mk(1.f, 0.f, 0.f), hmat = cur_hi.z;
+                  best = t, tag = depth, nhits++;
+                }
+              }
+            }
+          }
+        }
+        pc += 32u;
+      }
+      if (op >= OP_SPHERE && op <= OP_MEDIUM) cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc);
+    }
+  }
+  if (COUNT) {
+    atomicAdd(&counters[0], (unsigned long long)cnt.aabb);
+    atomicAdd(&counters[1], (unsigned long long)cnt.prim);
+    atomicAdd(&counters[2], (unsigned long long)cnt.shaded);
+    atomicAdd(&counters[3], (unsigned long long)cnt.rays);
+    atomicAdd(&counters[4], (unsigned long long)total_draws);
+    if (lane == 0) {
+      unsigned long long* sched = counters + 8;
+      atomicAdd(&sched[0], (unsigned long long)n_box_it), atomicAdd(&sched[1], (unsigned long long)n_box_lanes);
+      atomicAdd(&sched[2], (unsigned long long)n_slow_it), atomicAdd(&sched[3], (unsigned long long)n_slow_lanes);
+      atomicAdd(&sched[4], (unsigned long long)n_shade), atomicAdd(&sched[5], (unsigned long long)n_shade_lanes);
+      atomicAdd(&sched[6], (unsigned long long)n_refill);
+    }
+  }
+#undef RT_FETCH_LO
+#undef RT_FETCH_HI
+#undef SLOT_U
+#undef SLOT_F
+}
+
+}  // namespace rtg

@@ -238,15 +238,18 @@ RT_DEV int32_t f32_as_i32(float f) {  // Rust `as i32`: saturating, NaN -> 0
   return (int32_t)f;
 }
 
-RT_DEV float perlin_noise(const DevScene& sc, V3 p) {  // perlin.rs:49-64 + :31-47
+__device__ __attribute__((noinline)) float perlin_noise(const DevScene& sc, V3 p) {  // perlin.rs:49-64 + :31-47
   V3 ijk = mk(__builtin_floorf(p.x), __builtin_floorf(p.y), __builtin_floorf(p.z));
   V3 uvw = vsub(p, ijk);
   uint32_t bi = (uint32_t)f32_as_i32(ijk.x), bj = (uint32_t)f32_as_i32(ijk.y), bk = (uint32_t)f32_as_i32(ijk.z);
   V3 uvw3 = vmul(vmul(uvw, uvw), vsub(splat(3.f), smul(2.f, uvw)));
   V3 uvw3_inv = vsub(splat(1.f), uvw3);
   float accum = 0.f;
+#pragma unroll 1
   for (uint32_t i = 0; i < 2; i++)
+#pragma unroll 1
     for (uint32_t j = 0; j < 2; j++)
+#pragma unroll 1
       for (uint32_t k = 0; k < 2; k++) {
         uint32_t ix = sc.perlin_perm[(bi + i) & 255u];
         uint32_t iy = sc.perlin_perm[256u + ((bj + j) & 255u)];
@@ -263,6 +266,7 @@ RT_DEV float perlin_noise(const DevScene& sc, V3 p) {  // perlin.rs:49-64 + :31-
 
 RT_DEV float perlin_turb(const DevScene& sc, V3 p, int depth) {  // perlin.rs:66-75
   float accum = 0.f, weight = 1.f;
+#pragma unroll 1
   for (int i = 0; i < depth; i++) {
     accum += weight * perlin_noise(sc, p);
     weight *= 0.5f;
@@ -271,7 +275,12 @@ RT_DEV float perlin_turb(const DevScene& sc, V3 p, int depth) {  // perlin.rs:66
   return __builtin_fabsf(accum);
 }
 
-RT_DEV V3 texture_eval(const DevScene& sc, uint32_t idx, V3 p) {
+// out of line on purpose: Perlin turbulence (7 octaves x 8 gradient fetches) is a rare path and would
+// otherwise dominate the register allocation of every kernel that can reach it
+__device__ __attribute__((noinline)) V3 texture_eval(const DevScene& sc, uint32_t idx, V3 p) {
+#ifdef RT_STUB_TEX
+  return p;
+#endif
   for (;;) {
     uint4 lo = sc.tex[2 * idx], hi = sc.tex[2 * idx + 1];
     uint32_t kind = hi.w;

@@ -14,6 +14,7 @@
 #include "../../include/rtiow_gpu.h"
 #include "rt_persistent.h"
 #include "rt_pool.h"
+#include "rt_pool_full.h"
 #include "rt_trace.h"
 #include "scene_builder.h"
 
@@ -146,6 +147,8 @@ struct rtg_scene {
   unsigned long long* d_counters = nullptr;  // [0..4] N/P/H/rays/draws, [7] = work-queue head (persistent kernel)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int num_cus = 0;
+  float* d_stack = nullptr;     // full-feature pool kernel: per-wave transform stacks
+  size_t stack_bytes = 0;
   uint32_t* d_slots = nullptr;  // ray-pool path slots when they live in global memory
   size_t slots_bytes = 0;
   int slots_in_lds = 0;         // RTG_SLOTS_LDS=1: keep the path slots in LDS (8 waves/CU)
@@ -274,9 +277,72 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
   return e;
 }
 
+static hipError_t grow(void** buf, size_t* have, size_t need) {
+  if (need <= *have) return hipSuccess;
+  if (*buf) (void)hipFree(*buf);
+  *buf = nullptr, *have = 0;
+  hipError_t e = hipMalloc(buf, need);
+  if (e == hipSuccess) *have = need;
+  return e;
+}
+
+// Full-feature scenes, ray-pool kernel (rt_pool_full.h).  Returns hipErrorNotSupported when the sample
+// scratch would not fit: the caller then uses the baseline kernel.
+template <bool COUNT>
+static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const DevParams& d, float* d_out,
+                                   hipStream_t stream) {
+  uint32_t tiles_x = (d.nx + d.tile_w - 1) / d.tile_w, tiles_y = (d.ny + d.tile_h - 1) / d.tile_h;
+  uint32_t tiles = tiles_x * tiles_y;
+  uint32_t owned = tiles > d.rank ? (tiles - d.rank + d.nranks - 1) / d.nranks : 0;
+  const uint64_t pix_work = (uint64_t)owned * d.tile_w * d.tile_h;
+  const uint64_t scratch_need = pix_work * d.ns * 3 * sizeof(float);
+  const uint64_t total_work = pix_work * d.ns;
+  if (scratch_need > (16ull << 30) || total_work > 0xfffffffeull) return hipErrorNotSupported;
+  if (pix_work == 0) return hipSuccess;
+  const int bt = s->block_threads;
+  const uint32_t waves = (uint32_t)bt / 64;
+  hipError_t e = grow((void**)&s->d_scratch, &s->scratch_bytes, scratch_need);
+  if (e != hipSuccess) return e;
+  ChunkMode cm{s->d_scratch, 1u, d.ns, (uint32_t)pix_work};
+  uint32_t* queue = (uint32_t*)(s->d_counters + 7);
+  e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream);
+  if (e != hipSuccess) return e;
+  const bool use_lds = full_pool_lds_bytes(s->n_prog, waves, true) <= 72 * 1024;  // two workgroups per CU
+  const size_t lds = full_pool_lds_bytes(s->n_prog, waves, use_lds);
+  const bool tex = (s->features & FEAT_TEXTURE) != 0;
+  auto kernel = use_lds ? (tex ? render_full_pool<true, true, COUNT> : render_full_pool<true, false, COUNT>)
+                        : (tex ? render_full_pool<false, true, COUNT> : render_full_pool<false, false, COUNT>);
+  e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  int per_cu = s->wg_per_cu;
+  if (per_cu <= 0) {
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, bt, lds);
+    if (e != hipSuccess) return e;
+  }
+  if (per_cu < 1) per_cu = 1;
+  uint64_t want = (total_work + (uint64_t)waves * POOL - 1) / ((uint64_t)waves * POOL);
+  uint32_t grid = (uint32_t)std::min<uint64_t>(want ? want : 1, (uint64_t)s->num_cus * per_cu);
+  e = grow((void**)&s->d_slots, &s->slots_bytes, (size_t)grid * waves * POOL * FPOOL_FIELDS * sizeof(uint32_t));
+  if (e != hipSuccess) return e;
+  e = grow((void**)&s->d_stack, &s->stack_bytes, (size_t)grid * waves * MAX_XFORM_DEPTH * 6 * 64 * sizeof(float));
+  if (e != hipSuccess) return e;
+  if (getenv("RTG_VERBOSE"))
+    fprintf(stderr, "[rtg] full pool: grid %u x %d threads, %d WG/CU, lds %zu B (program staged: %d)\n", grid, bt, per_cu, lds,
+            (int)use_lds);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(bt), lds, stream, s->dev, cam, d, d_out, (uint32_t)total_work, queue,
+                     s->d_counters, s->pool_tune, cm, s->d_slots, s->d_stack);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(fold_samples_kernel, dim3((uint32_t)((pix_work + 255) / 256)), dim3(256), 0, stream, d, cm, d_out);
+  return hipGetLastError();
+}
+
 template <bool COUNT>
 static void launch_render(rtg_scene* s, const DevCamera& cam, const DevParams& d, float* d_out,
                           hipStream_t stream) {
+  if (s->features != 0 && s->kernel_version >= 3 && d.nx <= 0xffffu && d.ny <= 0xffffu) {
+    if (launch_full_pool<COUNT>(s, cam, d, d_out, stream) != hipErrorNotSupported) return;
+  }
   if (s->features == 0 && s->kernel_version >= 3 && d.nx <= 0xffffu && d.ny <= 0xffffu) {
     (void)launch_pool<COUNT>(s, cam, d, d_out, stream);
     return;
@@ -549,6 +615,7 @@ void rtg_scene_destroy(rtg_scene* s) {
   if (s->d_counters) (void)hipFree(s->d_counters);
   if (s->d_scratch) (void)hipFree(s->d_scratch);
   if (s->d_slots) (void)hipFree(s->d_slots);
+  if (s->d_stack) (void)hipFree(s->d_stack);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   delete s;
