@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel (default 50 * gpus)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xDEADBEEF)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true",
+                    help="rank 0 also renders the frame unsharded and checks the reduced frame bit-for-bit")
     args = ap.parse_args()
 
     import torch
@@ -79,10 +81,17 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # RTG_BENCH_BACKEND=gloo is a TEST hook: it lets the N>1 code path run with several ranks on ONE GPU
+    # (RCCL refuses two ranks per device); the framebuffer is then reduced through host memory.
+    backend = os.environ.get("RTG_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     pkg = graft.load_package()
     gpu = pkg.load()
@@ -91,7 +100,7 @@ def main():
 
     b = gpu.builder()
     objs, cam, _ = pkg.scenes.random_scene(b, nx, ny)
-    scene = b.scene(objs, device=local_rank)
+    scene = b.scene(objs, device=dev_index)
     info = scene.info()
 
     fb = torch.zeros((ny, nx, 3), dtype=torch.float32, device=dev)
@@ -101,7 +110,12 @@ def main():
         p = pkg.make_params(nx, ny, spp, seed=args.seed, rank=rank, nranks=world, flags=flags)
         st = scene.par_cast_device(cam, p, ctypes.c_void_p(fb.data_ptr()), stream, want_stats=True)
         if world > 1:
-            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+            if backend == "nccl":
+                dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)   # ONE collective: float3 framebuffer over RCCL/xGMI
+            else:
+                host = fb.cpu()
+                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+                fb.copy_(host)
         return st
 
     # counting pass (untimed): the instrumented kernel gives N/P/H for the algorithmic byte model
@@ -118,6 +132,17 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    verified = None
+    if args.verify:
+        fb.zero_()
+        step()
+        sync()
+        if rank == 0:
+            whole = torch.zeros_like(fb)
+            p1 = pkg.make_params(nx, ny, spp, seed=args.seed)
+            scene.par_cast_device(cam, p1, ctypes.c_void_p(whole.data_ptr()), stream, want_stats=True)
+            verified = bool(torch.equal(whole.view(torch.int32), fb.view(torch.int32)))
 
     sync()
     t0 = time.perf_counter()
@@ -176,6 +201,8 @@ def main():
                 "counters_per_launch": {k: cst[k] for k in ("aabb_tests", "prim_tests", "shaded_hits", "rays", "draws")},
             },
         }
+        if verified is not None:
+            line["verified_bit_exact_vs_unsharded"] = verified
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pkg, nx, ny)
         print(json.dumps(line))

@@ -245,3 +245,23 @@ def test_scene_reuse_across_sizes_and_sample_counts(pkg, gpu, oracle):
     for (nx, ny, ns) in [(64, 64, 1), (64, 64, 2), (96, 64, 1), (96, 64, 9), (32, 16, 40), (96, 64, 3)]:
         cg = gpu.camera_look(pkg.scenes.v(13, 2, 3), pkg.scenes.v(0, 0, 0), pkg.scenes.v(0, 1, 0), 20.0, nx / ny, 0.1, 10.0)
         assert_bit_equal(sg.par_cast(cg, nx, ny, ns), so.par_cast(cg, nx, ny, ns), "%dx%dx%d" % (nx, ny, ns))
+
+
+def test_bench_multi_rank_path_on_one_gpu(tmp_path):
+    """bench.py's N>1 leg (tile sharding by rank + framebuffer reduce + max-over-ranks timing), run as
+    2 ranks that share the single GPU of this box (RTG_BENCH_BACKEND=gloo test hook: RCCL refuses two
+    ranks per device).  --verify makes rank 0 compare the reduced frame with an unsharded render."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RTG_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--nx", "320", "--ny", "192", "--verify", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["verified_bit_exact_vs_unsharded"] is True
+    assert line["config"]["workload"].endswith("x100spp") and line["scaling"] == "weak"
+    assert line["roofline"]["bound"] == "hbm" and line["value"] > 0
