@@ -40,6 +40,7 @@ constexpr uint32_t F_FLIP = 1u << 9;        // SPHERE/RECT: normal = -normal (od
 constexpr uint32_t F_AXIS_SHIFT = 10;       // RECT: bits 10-11 = orthogonal axis (0/1/2)
 constexpr uint32_t F_UNDER_BVH = 1u << 12;  // MEDIUM: lives below a Bvh node (hit-merge rule of bvh.rs:104-112)
 constexpr uint32_t F_BVH_ROOT = 1u << 13;   // BOX: root of an outermost Bvh (a Bvh not nested below another Bvh)
+constexpr uint32_t F_MATKIND_SHIFT = 16;    // SPHERE/RECT/MEDIUM: bits 16-18 = MatKind of the record's material (copy, for schedulers)
 constexpr uint32_t F_KIND_SHIFT = 8;        // PUSH/POP: bits 8-10 = XformKind
 
 enum XformKind : uint32_t {

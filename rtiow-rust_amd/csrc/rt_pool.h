@@ -25,10 +25,11 @@
 
 namespace rtg {
 
-constexpr uint32_t POOL = 128;           // path slots per wave
+constexpr uint32_t POOL = 192;           // path slots per wave: 64 in lanes + 128 waiting, so one wait list always holds >= 64
 constexpr uint32_t POOL_FIELDS = 20;     // dwords per slot (SoA: field f of slot j at [f * POOL + j])
 constexpr uint32_t WORK_BLOCK = 2048;    // work items a wave reserves per global atomic
 constexpr uint32_t SLOT_NEED_PIXEL = 0xfffffffeu;  // best_pc marker: slot holds no ray yet
+constexpr uint32_t SLOT_ENDED = 0xfffffffdu;       // best_pc marker: path ended in a SCATTER pass, colour parked in accum
 
 enum PoolField : uint32_t {
   PF_O = 0, PF_D = 3, PF_BEST = 6, PF_BEST_PC = 7, PF_STRENGTH = 8, PF_ACCUM = 11, PF_BOUNCES = 14, PF_SAMPLE = 15,
@@ -84,8 +85,8 @@ struct PoolTuning {
 inline size_t pool_lds_bytes(uint32_t n_prog, uint32_t n_mat, uint32_t waves, bool stage_program, bool slots_in_lds) {
   size_t b = stage_program ? ((size_t)n_prog * 32 + (size_t)n_mat * 32) : 0;
   if (slots_in_lds) b += (size_t)waves * POOL * POOL_FIELDS * 4;  // slots
-  b += (size_t)waves * POOL * 2 * 4;                              // T-list + S-list
-  return b;
+  b += (size_t)waves * POOL * 3 * 2;                              // T-, S- and E-list (u16 slot ids)
+  return (b + 15) & ~(size_t)15;
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -104,18 +105,26 @@ RT_DEV uint4 fetch_hi_global(const DevScene& sc, uint32_t idx) {  // byte-offset
 #ifndef RT_POOL_WAVES_PER_EU
 #define RT_POOL_WAVES_PER_EU 1
 #endif
+// Two wait lists, two pass types.  A finished ray is classified by what its path does next:
+//   E ("end")     the path ends here: a miss, a DiffuseLight hit (the sky dome ends 38 % of book-1's
+//                 rays), a path ended by a SCATTER pass, or a slot without a ray.  The END pass books the
+//                 sample colour, pulls the next work item and generates its camera ray (event 0).
+//   S ("scatter") Lambertian / Metal / Dielectric / Isotropic hit: the SCATTER pass rebuilds the hit
+//                 record and runs Material::scatter.
+// Each pass type runs 64 lanes wide over slots of ITS class, so a wave no longer issues the union of
+// the scatter code and the camera code for every batch of finished rays.  The class of a hit is read
+// from the winning SPHERE record (the flattener copies the material kind into its flag word).
 template <bool USE_LDS, bool SLOTS_LDS, bool COUNT>
-__global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void render_lean_pool(DevScene sc, DevCamera cam, DevParams P,
-                                                        float* __restrict__ out, uint32_t total_work,
-                                                        uint32_t* __restrict__ queue, unsigned long long* counters,
-                                                        PoolTuning tune, ChunkMode cm, uint32_t* __restrict__ g_slots) {
+__global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void render_lean_pool(
+    DevScene sc, DevCamera cam, DevParams P, float* __restrict__ out, uint32_t total_work, uint32_t* __restrict__ queue,
+    unsigned long long* counters, PoolTuning tune, ChunkMode cm, uint32_t* __restrict__ g_slots) {
   extern __shared__ uint4 s_mem[];
   const uint32_t n_prog = sc.n_prog;
   const uint32_t staged = USE_LDS ? 2u * n_prog + 2u * sc.n_mat : 0u;  // uint4 units
   // Program counters are BYTE offsets (16 r) into the staged lo[] array; hi[] follows at +16 n.  A step
   // needs no shift (ds_read_b128 pc ; ds_read_b128 pc + hi_off) and BOX skip pointers are stored
-  // pre-multiplied.  SoA (not 32-byte AoS records) on purpose: a b128 gather of 16-byte packets then
-  // spreads over all 64 LDS banks, an AoS layout would use only every other 4-bank group per load.
+  // pre-multiplied.  SoA (not 32-byte AoS records): a b128 gather of 16-byte packets then spreads over
+  // all 64 LDS banks.
   const uint32_t hi_off = 16u * n_prog;
   if (USE_LDS) {
     for (uint32_t i = threadIdx.x; i < n_prog; i += blockDim.x) {
@@ -135,33 +144,35 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
   uint32_t* slot = SLOTS_LDS ? pool_base + wave * (POOL * POOL_FIELDS)
                              : g_slots + ((size_t)blockIdx.x * n_waves + wave) * (POOL * POOL_FIELDS);
   float* slotf = reinterpret_cast<float*>(slot);
-  uint32_t* tlist = pool_base + (SLOTS_LDS ? n_waves * (POOL * POOL_FIELDS) : 0u) + wave * (2u * POOL);
-  uint32_t* slist = tlist + POOL;
+  uint16_t* tlist = reinterpret_cast<uint16_t*>(pool_base + (SLOTS_LDS ? n_waves * (POOL * POOL_FIELDS) : 0u)) + wave * (3u * POOL);
+  uint16_t* slist = tlist + POOL;
+  uint16_t* elist = slist + POOL;
 #define SLOT_U(f_, j_) slot[(f_)*POOL + (j_)]
 #define SLOT_F(f_, j_) slotf[(f_)*POOL + (j_)]
-  // all slots start as "need a pixel", all on the S-list
+  // all slots start as "need a work item", all on the E-list
   for (uint32_t j = lane; j < POOL; j += 64u) {
     SLOT_U(PF_BEST_PC, j) = SLOT_NEED_PIXEL;
-    slist[j] = j;
+    elist[j] = (uint16_t)j;
   }
   __syncthreads();  // program staged, pools initialised (the only workgroup barrier)
 
   const uint64_t seed = ((uint64_t)P.seed_hi << 32) | P.seed_lo;
   const float t_near = P.t_near;
-  uint32_t t_count = 0, s_count = POOL, n_dead = 0;  // wave-uniform list sizes / retired slots
-  uint32_t w_next = 0, w_end = 0;                    // this wave's reserved range of work items
-  bool exhausted = false;                            // the global counter ran past total_work
+  uint32_t t_count = 0, s_count = 0, e_count = POOL, n_dead = 0;  // wave-uniform list sizes / retired slots
+  uint32_t w_next = 0, w_end = 0;                                  // this wave's reserved range of work items
+  bool exhausted = false;                                          // the global counter ran past total_work
 
   // ---- per-lane traversal state ---------------------------------------------------------------
   uint32_t my_slot = 0;
   bool have_ray = false;  // lane holds a ray (traversing or parked at a SPHERE record)
   V3 o = mk(0.f, 0.f, 0.f), d = o, inv = o;
-  uint32_t pc = 0, best_pc = NO_HIT;
+  uint32_t pc = 0, best_pc = NO_HIT, best_flags = 0;
   float best = F32_MAX;
   uint4 cur_lo = make_uint4(0, 0, 0, 0), cur_hi = make_uint4(0, 0, 0, OP_END);
   Counts cnt = {0, 0, 0, 0};
   uint32_t total_draws = 0;
   uint32_t n_box_it = 0, n_box_lanes = 0, n_sph_it = 0, n_sph_lanes = 0, n_shade = 0, n_shade_lanes = 0, n_refill = 0;
+  uint32_t n_end = 0, n_end_lanes = 0;
   unsigned long long t_shade = 0, t_serv = 0, t_box = 0, t_sph = 0, t_mark = 0, t_mark2 = 0;  // COUNT: s_memtime shares
 
   for (;;) {
@@ -172,142 +183,177 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
     // ============================== SERVICE ======================================================
     if (64u - n_busy >= tune.refill_min || n_busy == 0) {
       if (COUNT) t_mark = RT_TICK();
-      // (1) finish: rays that reached END hand their result to their slot and join the S-list
+      // (1) finish: rays that reached END hand (best, best_pc) to their slot and join the E- or S-list
       {
         const bool fin = have_ray && op == OP_END;
-        const uint64_t m_fin = __builtin_amdgcn_ballot_w64(fin);
+        const bool to_e = fin && (best_pc == NO_HIT || ((best_flags >> F_MATKIND_SHIFT) & 7u) == MAT_DIFFUSE_LIGHT);
+        const bool to_s = fin && !to_e;
+        const uint64_t m_e = __builtin_amdgcn_ballot_w64(to_e), m_s = __builtin_amdgcn_ballot_w64(to_s);
         if (fin) {
           SLOT_F(PF_BEST, my_slot) = best;
           SLOT_U(PF_BEST_PC, my_slot) = best_pc;
-          slist[s_count + lane_rank(m_fin)] = my_slot;
+          if (to_e) elist[e_count + lane_rank(m_e)] = (uint16_t)my_slot;
+          else slist[s_count + lane_rank(m_s)] = (uint16_t)my_slot;
           have_ray = false;
         }
-        s_count += (uint32_t)__builtin_popcountll(m_fin);
+        e_count += (uint32_t)__builtin_popcountll(m_e);
+        s_count += (uint32_t)__builtin_popcountll(m_s);
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      // (2) shade: a full-width pass whenever 64 slots wait, or when nothing else can make progress
-      while (s_count >= 64u || (s_count > 0 && t_count == 0 && n_busy == 0)) {
+      const bool starving = (t_count == 0 && n_busy == 0);  // nothing to traverse: run partial passes too
+      // (2a) SCATTER pass: Material::scatter for 64 hits on scattering materials
+      while (s_count >= 64u || (s_count > 0 && starving)) {
         const uint32_t take = s_count < 64u ? s_count : 64u;
         s_count -= take;
         if (COUNT) n_shade++, n_shade_lanes += take, t_mark2 = RT_TICK();
-        uint32_t st = ST_DEAD, j = 0;
-        V3 so = mk(0.f, 0.f, 0.f), sd = so, strength = so, accum = so, col = so;
-        uint32_t bounces = 0, s = 0, x = 0, row = 0;
+        bool live = false, ended = false;
+        uint32_t j = 0;
         if (lane < take) {
           j = slist[s_count + lane];
+          const uint32_t bpc = SLOT_U(PF_BEST_PC, j);
+          V3 so = mk(SLOT_F(PF_O, j), SLOT_F(PF_O + 1, j), SLOT_F(PF_O + 2, j));
+          V3 sd = mk(SLOT_F(PF_D, j), SLOT_F(PF_D + 1, j), SLOT_F(PF_D + 2, j));
+          V3 strength = mk(SLOT_F(PF_STRENGTH, j), SLOT_F(PF_STRENGTH + 1, j), SLOT_F(PF_STRENGTH + 2, j));
+          V3 accum = mk(SLOT_F(PF_ACCUM, j), SLOT_F(PF_ACCUM + 1, j), SLOT_F(PF_ACCUM + 2, j));
+          uint32_t bounces = SLOT_U(PF_BOUNCES, j);
+          const uint32_t s = SLOT_U(PF_SAMPLE, j), xy = SLOT_U(PF_XY, j);
+          const float hb = SLOT_F(PF_BEST, j);
+          // ---------------- color() loop body, lib.rs:73-97, for a hit on a scattering material ----------
+          SampleRng rng;
+          rng.init(seed, (P.ny - 1u - (xy >> 16)) * P.nx + (xy & 0xffffu), s);
+          rng.set_event(bounces + 1u);
+          if (COUNT) cnt.shaded++;
+          const uint4 plo = RT_FETCH_LO(bpc), phi = RT_FETCH_HI(bpc);
+          V3 off = mk(u2f(plo.x), u2f(plo.y), u2f(plo.z));
+          V3 lo_o = so;
+          if (phi.w & F_TRANSLATE) lo_o = vsub(so, off);       // object.rs:275-278
+          V3 hp = vadd(lo_o, smul(hb, sd));                    // ray.rs:15
+          V3 hn = sdiv(hp, u2f(plo.w));                        // object.rs:104
+          if (phi.w & F_TRANSLATE) hp = vadd(hp, off);         // object.rs:279-282
+          if (phi.w & F_FLIP) hn = vneg(hn);                   // object.rs:249-252
+          const uint4 mlo = RT_FETCH_MAT(2u * phi.z), mhi = RT_FETCH_MAT(2u * phi.z + 1u);
+          const uint32_t kind = mhi.w & 0xffu;
+          const float param = u2f(mlo.w);
+          const V3 mcol = mk(u2f(mlo.x), u2f(mlo.y), u2f(mlo.z));
+          accum = vadd(accum, vmul(strength, mk(0.f, 0.f, 0.f)));  // lib.rs:76 with emitted = 0 (material.rs:126)
+          V3 nd = mk(0.f, 0.f, 0.f), att = mcol;
+          bool scattered = true;
+          // Lambertian, Metal and Isotropic each draw exactly one in_unit_sphere before any other draw of
+          // this event (reflect() consumes no randomness): ONE rejection loop serves all three.
+          V3 rs = mk(0.f, 0.f, 0.f);
+          if (kind != MAT_DIELECTRIC) rs = in_unit_sphere(rng);
+          if (kind == MAT_LAMBERTIAN) {  // material.rs:57-65
+            V3 target = vadd(vadd(hp, hn), rs);
+            nd = vsub(target, hp);
+          } else if (kind == MAT_METAL) {  // material.rs:66-80
+            V3 refl = reflect(vunit(sd), hn);
+            nd = vadd(refl, smul(param, rs));
+            scattered = vdot(nd, hn) > 0.f;
+          } else if (kind == MAT_DIELECTRIC) {  // material.rs:81-107
+            V3 outward;
+            float ni_over_nt, cosine;
+            float dn = vdot(sd, hn);
+            if (dn > 0.f) {
+              outward = vneg(hn);
+              ni_over_nt = param;
+              cosine = param * dn / vlen(sd);
+            } else {
+              outward = hn;
+              ni_over_nt = 1.0f / param;
+              cosine = -dn / vlen(sd);
+            }
+            V3 uv = vunit(sd);  // refract, vec3.rs:321-330
+            float dt = vdot(uv, outward);
+            float disc = 1.0f - ni_over_nt * ni_over_nt * (1.f - dt * dt);
+            bool refracted = disc > 0.f;
+            if (refracted) {
+              nd = vsub(smul(ni_over_nt, vsub(uv, smul(dt, outward))), smul(__builtin_sqrtf(disc), outward));
+              refracted = rng.gen_f32() >= schlick(cosine, param);  // material.rs:97: draw only if Some
+            }
+            if (!refracted) nd = reflect(sd, hn);
+            att = splat(1.f);
+          } else {  // Isotropic, material.rs:109-116
+            nd = rs;
+          }
+          if (COUNT) total_draws += rng.draws;
+          if (scattered) {
+            strength = vmul(strength, att);  // lib.rs:87
+            if (bounces != P.max_bounces) {  // lib.rs:93-97
+              bounces += 1;
+              live = true;
+            }
+          }
+          if (live) {
+            SLOT_F(PF_O, j) = hp.x, SLOT_F(PF_O + 1, j) = hp.y, SLOT_F(PF_O + 2, j) = hp.z;
+            SLOT_F(PF_D, j) = nd.x, SLOT_F(PF_D + 1, j) = nd.y, SLOT_F(PF_D + 2, j) = nd.z;
+            SLOT_F(PF_STRENGTH, j) = strength.x, SLOT_F(PF_STRENGTH + 1, j) = strength.y, SLOT_F(PF_STRENGTH + 2, j) = strength.z;
+            SLOT_U(PF_BOUNCES, j) = bounces;
+            if (COUNT) cnt.rays++;
+          } else {  // both early returns of color() yield accum (lib.rs:90,94): the END pass books it
+            ended = true;
+            SLOT_U(PF_BEST_PC, j) = SLOT_ENDED;
+          }
+          SLOT_F(PF_ACCUM, j) = accum.x, SLOT_F(PF_ACCUM + 1, j) = accum.y, SLOT_F(PF_ACCUM + 2, j) = accum.z;
+        }
+        const uint64_t m_live = __builtin_amdgcn_ballot_w64(live), m_ended = __builtin_amdgcn_ballot_w64(ended);
+        if (live) tlist[t_count + lane_rank(m_live)] = (uint16_t)j;
+        if (ended) elist[e_count + lane_rank(m_ended)] = (uint16_t)j;
+        t_count += (uint32_t)__builtin_popcountll(m_live);
+        e_count += (uint32_t)__builtin_popcountll(m_ended);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (COUNT) t_shade += RT_TICK() - t_mark2;
+      }
+      // (2b) END pass: book the sample colour, next work item, camera ray
+      while (e_count >= 64u || (e_count > 0 && starving && t_count == 0)) {
+        const uint32_t take = e_count < 64u ? e_count : 64u;
+        e_count -= take;
+        if (COUNT) n_end++, n_end_lanes += take, t_mark2 = RT_TICK();
+        uint32_t st = ST_DEAD, j = 0, s = 0, x = 0, row = 0;
+        V3 col = mk(0.f, 0.f, 0.f);
+        if (lane < take) {
+          j = elist[e_count + lane];
           const uint32_t bpc = SLOT_U(PF_BEST_PC, j);
           if (bpc == SLOT_NEED_PIXEL) {
             st = ST_NEED_PIXEL;
           } else {
-            st = ST_SHADE;
-            so = mk(SLOT_F(PF_O, j), SLOT_F(PF_O + 1, j), SLOT_F(PF_O + 2, j));
-            sd = mk(SLOT_F(PF_D, j), SLOT_F(PF_D + 1, j), SLOT_F(PF_D + 2, j));
-            strength = mk(SLOT_F(PF_STRENGTH, j), SLOT_F(PF_STRENGTH + 1, j), SLOT_F(PF_STRENGTH + 2, j));
-            accum = mk(SLOT_F(PF_ACCUM, j), SLOT_F(PF_ACCUM + 1, j), SLOT_F(PF_ACCUM + 2, j));
-            col = mk(SLOT_F(PF_COL, j), SLOT_F(PF_COL + 1, j), SLOT_F(PF_COL + 2, j));
-            bounces = SLOT_U(PF_BOUNCES, j), s = SLOT_U(PF_SAMPLE, j);
+            s = SLOT_U(PF_SAMPLE, j);
             const uint32_t xy = SLOT_U(PF_XY, j);
             x = xy & 0xffffu, row = xy >> 16;
-            const float hb = SLOT_F(PF_BEST, j);
-            // ---------------- color() loop body, lib.rs:73-97 ----------------
-            SampleRng rng;
-            rng.init(seed, (P.ny - 1u - row) * P.nx + x, s);
-            rng.set_event(bounces + 1u);
-            bool ended = true;
             V3 result = mk(0.f, 0.f, 0.f);  // lib.rs:100: a miss is black, accum is discarded
             if (bpc != NO_HIT) {
-              if (COUNT) cnt.shaded++;
-              const uint4 plo = RT_FETCH_LO(bpc), phi = RT_FETCH_HI(bpc);
-              V3 off = mk(u2f(plo.x), u2f(plo.y), u2f(plo.z));
-              V3 lo_o = so;
-              if (phi.w & F_TRANSLATE) lo_o = vsub(so, off);
-              V3 hp = vadd(lo_o, smul(hb, sd));
-              V3 hn = sdiv(hp, u2f(plo.w));
-              if (phi.w & F_TRANSLATE) hp = vadd(hp, off);
-              if (phi.w & F_FLIP) hn = vneg(hn);
-              const uint4 mlo = RT_FETCH_MAT(2u * phi.z), mhi = RT_FETCH_MAT(2u * phi.z + 1u);
-              const uint32_t kind = mhi.w & 0xffu;
-              const float param = u2f(mlo.w);
-              const V3 mcol = mk(u2f(mlo.x), u2f(mlo.y), u2f(mlo.z));
-              V3 emitted = mk(0.f, 0.f, 0.f);
-              if (kind == MAT_DIFFUSE_LIGHT) emitted = smul(param, mcol);
-              accum = vadd(accum, vmul(strength, emitted));
-              V3 nd = mk(0.f, 0.f, 0.f), att = mcol;
-              bool scattered = true;
-              V3 rs = mk(0.f, 0.f, 0.f);
-              if (kind == MAT_LAMBERTIAN || kind == MAT_METAL || kind == MAT_ISOTROPIC) rs = in_unit_sphere(rng);
-              if (kind == MAT_LAMBERTIAN) {
-                V3 target = vadd(vadd(hp, hn), rs);
-                nd = vsub(target, hp);
-              } else if (kind == MAT_METAL) {
-                V3 refl = reflect(vunit(sd), hn);
-                nd = vadd(refl, smul(param, rs));
-                scattered = vdot(nd, hn) > 0.f;
-              } else if (kind == MAT_DIELECTRIC) {
-                V3 outward;
-                float ni_over_nt, cosine;
-                float dn = vdot(sd, hn);
-                if (dn > 0.f) {
-                  outward = vneg(hn);
-                  ni_over_nt = param;
-                  cosine = param * dn / vlen(sd);
-                } else {
-                  outward = hn;
-                  ni_over_nt = 1.0f / param;
-                  cosine = -dn / vlen(sd);
-                }
-                V3 uv = vunit(sd);
-                float dt = vdot(uv, outward);
-                float disc = 1.0f - ni_over_nt * ni_over_nt * (1.f - dt * dt);
-                bool refracted = disc > 0.f;
-                if (refracted) {
-                  nd = vsub(smul(ni_over_nt, vsub(uv, smul(dt, outward))), smul(__builtin_sqrtf(disc), outward));
-                  refracted = rng.gen_f32() >= schlick(cosine, param);
-                }
-                if (!refracted) nd = reflect(sd, hn);
-                att = splat(1.f);
-              } else if (kind == MAT_DIFFUSE_LIGHT) {
-                scattered = false;
-              } else {
-                nd = rs;
-              }
-              result = accum;
-              if (scattered) {
-                so = hp, sd = nd;
-                strength = vmul(strength, att);
-                if (bounces != P.max_bounces) {
-                  bounces += 1;
-                  ended = false;
-                }
+              const V3 accum = mk(SLOT_F(PF_ACCUM, j), SLOT_F(PF_ACCUM + 1, j), SLOT_F(PF_ACCUM + 2, j));
+              result = accum;  // SLOT_ENDED: color() already returned accum
+              if (bpc != SLOT_ENDED) {  // DiffuseLight hit: lib.rs:76 then scatter() == None (material.rs:108)
+                if (COUNT) cnt.shaded++;
+                const V3 strength = mk(SLOT_F(PF_STRENGTH, j), SLOT_F(PF_STRENGTH + 1, j), SLOT_F(PF_STRENGTH + 2, j));
+                const uint4 phi = RT_FETCH_HI(bpc);
+                const uint4 mlo = RT_FETCH_MAT(2u * phi.z);
+                const V3 emitted = smul(u2f(mlo.w), mk(u2f(mlo.x), u2f(mlo.y), u2f(mlo.z)));  // material.rs:120-128
+                result = vadd(accum, vmul(strength, emitted));
               }
             }
-            if (COUNT) total_draws += rng.draws;
-            if (ended) {
-              if (cm.scratch) {  // chunk mode: park the sample colour, folded in order afterwards
-                float* sp = cm.scratch + 3ull * ((size_t)s * cm.pix_work + pixel_to_work(P, x, row));
-                sp[0] = result.x, sp[1] = result.y, sp[2] = result.z;
-              } else {
-                col = vadd(col, result);
-              }
-              s++;
-              if (s == P.ns || (cm.scratch && s % cm.chunk == 0u)) {
-                if (!cm.scratch) {
-                  V3 px = sdiv(col, (float)P.ns);
-                  float* op_ = out + 3ull * ((size_t)row * P.nx + x);
-                  op_[0] = px.x, op_[1] = px.y, op_[2] = px.z;
-                }
-                st = ST_NEED_PIXEL;
-              } else {
-                st = ST_GEN;
-              }
+            if (cm.scratch) {  // chunk mode: park the sample colour, folded in order afterwards
+              float* sp = cm.scratch + 3ull * ((size_t)s * cm.pix_work + pixel_to_work(P, x, row));
+              sp[0] = result.x, sp[1] = result.y, sp[2] = result.z;
             } else {
-              st = ST_TRAV;
+              col = vadd(mk(SLOT_F(PF_COL, j), SLOT_F(PF_COL + 1, j), SLOT_F(PF_COL + 2, j)), result);  // vec3.rs:195-203
+            }
+            s++;
+            if (s == P.ns || (cm.scratch && s % cm.chunk == 0u)) {
+              if (!cm.scratch) {
+                V3 px = sdiv(col, (float)P.ns);  // lib.rs:374
+                float* op_ = out + 3ull * ((size_t)row * P.nx + x);
+                op_[0] = px.x, op_[1] = px.y, op_[2] = px.z;
+              }
+              st = ST_NEED_PIXEL;
+            } else {
+              st = ST_GEN;
             }
           }
         }
         // next work item.  The wave reserves WORK_BLOCK items at a time from the global counter (one
-        // returning atomic per ~WORK_BLOCK samples: a single counter word saturates near 88 dequeues/us on
-        // this chip, which one-atomic-per-shade-pass reached) and hands them out to its lanes locally.
+        // returning atomic per ~WORK_BLOCK samples: a single counter word saturates near 88 dequeues/us
+        // on this chip) and hands them out to its lanes locally.
         for (;;) {
           const uint64_t need = __builtin_amdgcn_ballot_w64(st == ST_NEED_PIXEL);
           if (need == 0) break;
@@ -344,32 +390,27 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           const uint32_t n_need = (uint32_t)__builtin_popcountll(need);
           w_next += n_need < avail ? n_need : avail;
         }
-        if (st == ST_GEN) {  // par_cast closure, lib.rs:366-371 (event 0)
+        const bool live = st == ST_GEN;
+        if (live) {  // par_cast closure, lib.rs:366-371 (event 0) and color()'s initial state, lib.rs:62-67
           const uint32_t y = P.ny - 1u - row;
           SampleRng rng;
           rng.init(seed, y * P.nx + x, s);
           float u = ((float)x + rng.gen_f32()) / (float)P.nx;
           float v = ((float)y + rng.gen_f32()) / (float)P.ny;
+          V3 so, sd;
           float time;
           get_ray(cam, u, v, rng, so, sd, time);
-          accum = mk(0.f, 0.f, 0.f), strength = splat(1.f), bounces = 0;
-          if (COUNT) total_draws += rng.draws;
-          st = ST_TRAV;
-        }
-        // write the paths back; live ones join the T-list
-        const bool live = st == ST_TRAV;
-        const uint64_t m_live = __builtin_amdgcn_ballot_w64(live);
-        if (live) {
+          if (COUNT) total_draws += rng.draws, cnt.rays++;
           SLOT_F(PF_O, j) = so.x, SLOT_F(PF_O + 1, j) = so.y, SLOT_F(PF_O + 2, j) = so.z;
           SLOT_F(PF_D, j) = sd.x, SLOT_F(PF_D + 1, j) = sd.y, SLOT_F(PF_D + 2, j) = sd.z;
-          SLOT_F(PF_STRENGTH, j) = strength.x, SLOT_F(PF_STRENGTH + 1, j) = strength.y, SLOT_F(PF_STRENGTH + 2, j) = strength.z;
-          SLOT_F(PF_ACCUM, j) = accum.x, SLOT_F(PF_ACCUM + 1, j) = accum.y, SLOT_F(PF_ACCUM + 2, j) = accum.z;
-          SLOT_F(PF_COL, j) = col.x, SLOT_F(PF_COL + 1, j) = col.y, SLOT_F(PF_COL + 2, j) = col.z;
-          SLOT_U(PF_BOUNCES, j) = bounces, SLOT_U(PF_SAMPLE, j) = s;
+          SLOT_F(PF_STRENGTH, j) = 1.f, SLOT_F(PF_STRENGTH + 1, j) = 1.f, SLOT_F(PF_STRENGTH + 2, j) = 1.f;
+          SLOT_F(PF_ACCUM, j) = 0.f, SLOT_F(PF_ACCUM + 1, j) = 0.f, SLOT_F(PF_ACCUM + 2, j) = 0.f;
+          if (!cm.scratch) SLOT_F(PF_COL, j) = col.x, SLOT_F(PF_COL + 1, j) = col.y, SLOT_F(PF_COL + 2, j) = col.z;
+          SLOT_U(PF_BOUNCES, j) = 0u, SLOT_U(PF_SAMPLE, j) = s;
           SLOT_U(PF_XY, j) = x | (row << 16);
-          tlist[t_count + lane_rank(m_live)] = j;
-          if (COUNT) cnt.rays++;
         }
+        const uint64_t m_live = __builtin_amdgcn_ballot_w64(live);
+        if (live) tlist[t_count + lane_rank(m_live)] = (uint16_t)j;
         t_count += (uint32_t)__builtin_popcountll(m_live);
         n_dead += take - (uint32_t)__builtin_popcountll(m_live);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -387,7 +428,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
             o = mk(SLOT_F(PF_O, my_slot), SLOT_F(PF_O + 1, my_slot), SLOT_F(PF_O + 2, my_slot));
             d = mk(SLOT_F(PF_D, my_slot), SLOT_F(PF_D + 1, my_slot), SLOT_F(PF_D + 2, my_slot));
             inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);  // aabb.rs:17
-            pc = 0, best = F32_MAX, best_pc = NO_HIT;
+            pc = 0, best = F32_MAX, best_pc = NO_HIT, best_flags = 0;
             cur_lo = RT_FETCH_LO(0), cur_hi = RT_FETCH_HI(0);
             have_ray = true;
           }
@@ -405,10 +446,10 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
     const uint64_t b_sph = __builtin_amdgcn_ballot_w64(op == OP_SPHERE);
     if (b_box != 0 && (uint32_t)__builtin_popcountll(b_sph) < tune.sphere_min) {
       // box run: tight loop, schedule re-evaluated once `box_leave` lanes have left the BOX state
+      if (COUNT) t_mark = RT_TICK();
       const uint32_t n0 = (uint32_t)__builtin_popcountll(b_box);
       const uint32_t floor_lanes = n0 > tune.box_leave ? n0 - tune.box_leave : 0u;
       uint32_t n_now;
-      if (COUNT) t_mark = RT_TICK();
       const bool neg_x = inv.x < 0.f, neg_y = inv.y < 0.f, neg_z = inv.z < 0.f;  // aabb.rs:20-23
       do {
         if (COUNT) n_box_it++;
@@ -441,6 +482,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
         if (sphere_hit_t(lo_o, d, u2f(cur_lo.w), t_near, best, t)) {
           best = t;
           best_pc = pc;
+          best_flags = cur_hi.w;
         }
         pc += 16u;
         cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc);
@@ -462,6 +504,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
       atomicAdd(&sched[6], (unsigned long long)n_refill);
       atomicAdd(&counters[16], t_shade), atomicAdd(&counters[17], t_serv - t_shade), atomicAdd(&counters[18], t_box),
           atomicAdd(&counters[19], t_sph);
+      atomicAdd(&counters[20], (unsigned long long)n_end), atomicAdd(&counters[21], (unsigned long long)n_end_lanes);
     }
   }
 #undef RT_FETCH_LO

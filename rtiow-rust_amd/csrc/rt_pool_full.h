@@ -31,9 +31,6 @@ inline size_t full_pool_lds_bytes(uint32_t n_prog, uint32_t waves, bool stage_pr
 
 // draw `idx` (0-based) of the stream (seed, pixel, sample, event): word idx%4 of Philox block idx/4
 __device__ __attribute__((noinline)) float event_draw_f32(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t event, uint32_t idx) {
-#ifdef RT_STUB_EVD
-  return 0.5f;
-#endif
   SampleRng r;
   r.init(seed, pixel, sample);
   r.set_event(event);

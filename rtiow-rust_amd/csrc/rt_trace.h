@@ -278,9 +278,6 @@ RT_DEV float perlin_turb(const DevScene& sc, V3 p, int depth) {  // perlin.rs:66
 // out of line on purpose: Perlin turbulence (7 octaves x 8 gradient fetches) is a rare path and would
 // otherwise dominate the register allocation of every kernel that can reach it
 __device__ __attribute__((noinline)) V3 texture_eval(const DevScene& sc, uint32_t idx, V3 p) {
-#ifdef RT_STUB_TEX
-  return p;
-#endif
   for (;;) {
     uint4 lo = sc.tex[2 * idx], hi = sc.tex[2 * idx + 1];
     uint32_t kind = hi.w;

@@ -772,8 +772,8 @@ int rtg_par_cast_device(rtg_scene* s, const rtg_camera* camera, const rtg_params
               q[2] ? (double)q[11] / q[2] : 0.);
       if (s->kernel_version >= 3)
         fprintf(stderr, "[rtg] pool schedule: box steps %llu (avg %.1f lanes), sphere passes %llu (avg %.1f lanes), shade passes %llu "
-                "(avg %.1f lanes), refills %llu\n", q[0], q[0] ? (double)q[1] / q[0] : 0.0, q[2], q[2] ? (double)q[3] / q[2] : 0.0,
-                q[4], q[4] ? (double)q[5] / q[4] : 0.0, q[6]);
+                "(avg %.1f lanes), end passes %llu (avg %.1f lanes), refills %llu\n", q[0], q[0] ? (double)q[1] / q[0] : 0.0, q[2],
+                q[2] ? (double)q[3] / q[2] : 0.0, q[4], q[4] ? (double)q[5] / q[4] : 0.0, q[12], q[12] ? (double)q[13] / q[12] : 0.0, q[6]);
       else
       fprintf(stderr, "[rtg] schedule: box passes %llu (avg %.1f lanes), sphere passes %llu (avg %.1f lanes), regen passes %llu "
               "(avg %.1f shade + %.1f gen lanes)\n", q[0], q[0] ? (double)q[1] / q[0] : 0.0, q[2], q[2] ? (double)q[3] / q[2] : 0.0,

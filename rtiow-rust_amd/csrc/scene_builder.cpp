@@ -199,12 +199,12 @@ static bool fuse_primitive(const SceneBuilder& b, uint32_t id, FlatScene* out, b
     } else if (o.kind == HostObject::SPHERE) {
       if (emit_it)
         push(out, off[0], off[1], off[2], o.f[0], 0, 0, o.mat,
-             OP_SPHERE | (have_t ? F_TRANSLATE : 0u) | (flip ? F_FLIP : 0u));
+             OP_SPHERE | (have_t ? F_TRANSLATE : 0u) | (flip ? F_FLIP : 0u) | (b.materials[o.mat].kind << F_MATKIND_SHIFT));
       return true;
     } else if (o.kind == HostObject::RECT && !have_t) {
       if (emit_it) {
         push(out, o.f[0], o.f[1], o.f[2], o.f[3], fbits(o.f[4]), 0, o.mat,
-             OP_RECT | ((uint32_t)o.axis << F_AXIS_SHIFT) | (flip ? F_FLIP : 0u));
+             OP_RECT | ((uint32_t)o.axis << F_AXIS_SHIFT) | (flip ? F_FLIP : 0u) | (b.materials[o.mat].kind << F_MATKIND_SHIFT));
         out->features |= FEAT_RECT;
       }
       return true;
