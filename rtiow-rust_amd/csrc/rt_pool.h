@@ -105,6 +105,9 @@ RT_DEV uint4 fetch_hi_global(const DevScene& sc, uint32_t idx) {  // byte-offset
 #ifndef RT_POOL_WAVES_PER_EU
 #define RT_POOL_WAVES_PER_EU 1
 #endif
+#ifndef RT_BOX_UNROLL
+#define RT_BOX_UNROLL 2
+#endif
 // Two wait lists, two pass types.  A finished ray is classified by what its path does next:
 //   E ("end")     the path ends here: a miss, a DiffuseLight hit (the sky dome ends 38 % of book-1's
 //                 rays), a path ended by a SCATTER pass, or a slot without a ray.  The END pass books the
@@ -175,6 +178,21 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
   uint32_t n_end = 0, n_end_lanes = 0;
   unsigned long long t_shade = 0, t_serv = 0, t_box = 0, t_sph = 0, t_mark = 0, t_mark2 = 0;  // COUNT: s_memtime shares
 
+#define RT_BOX_STEP() \
+        if (op == OP_BOX) { \
+          if (COUNT) cnt.aabb++; \
+          const f32x2 tx = (f32x2{u2f(cur_lo.x), u2f(cur_lo.y)} - f32x2{o.x, o.x}) * f32x2{inv.x, inv.x}; \
+          const f32x2 ty = (f32x2{u2f(cur_lo.z), u2f(cur_lo.w)} - f32x2{o.y, o.y}) * f32x2{inv.y, inv.y}; \
+          const f32x2 tz = (f32x2{u2f(cur_hi.x), u2f(cur_hi.y)} - f32x2{o.z, o.z}) * f32x2{inv.z, inv.z}; \
+          float ax = neg_x ? tx.y : tx.x, bx = neg_x ? tx.x : tx.y; \
+          float ay = neg_y ? ty.y : ty.x, by = neg_y ? ty.x : ty.y; \
+          float az = neg_z ? tz.y : tz.x, bz = neg_z ? tz.x : tz.y; \
+          float start = rs_max(t_near, rs_max(rs_max(ax, ay), az)); \
+          float end = rs_min(best, rs_min(rs_min(bx, by), bz)); \
+          pc = (end > start) ? pc + 16u : cur_hi.z; \
+          cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc); \
+          op = cur_hi.w & 0xffu; \
+        }
   for (;;) {
     uint32_t op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
     const uint64_t m_box = __builtin_amdgcn_ballot_w64(op == OP_BOX);
@@ -453,21 +471,10 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
       const bool neg_x = inv.x < 0.f, neg_y = inv.y < 0.f, neg_z = inv.z < 0.f;  // aabb.rs:20-23
       do {
         if (COUNT) n_box_it++;
-        if (op == OP_BOX) {  // Aabb::hit, aabb.rs:16-27
-          if (COUNT) cnt.aabb++;
-          // per axis (t0, t1) = ((min, max) - o) * inv as one packed subtract + one packed multiply
-          const f32x2 tx = (f32x2{u2f(cur_lo.x), u2f(cur_lo.y)} - f32x2{o.x, o.x}) * f32x2{inv.x, inv.x};
-          const f32x2 ty = (f32x2{u2f(cur_lo.z), u2f(cur_lo.w)} - f32x2{o.y, o.y}) * f32x2{inv.y, inv.y};
-          const f32x2 tz = (f32x2{u2f(cur_hi.x), u2f(cur_hi.y)} - f32x2{o.z, o.z}) * f32x2{inv.z, inv.z};
-          float ax = neg_x ? tx.y : tx.x, bx = neg_x ? tx.x : tx.y;
-          float ay = neg_y ? ty.y : ty.x, by = neg_y ? ty.x : ty.y;
-          float az = neg_z ? tz.y : tz.x, bz = neg_z ? tz.x : tz.y;
-          float start = rs_max(t_near, rs_max(rs_max(ax, ay), az));
-          float end = rs_min(best, rs_min(rs_min(bx, by), bz));
-          pc = (end > start) ? pc + 16u : cur_hi.z;
-          cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc);
-          op = cur_hi.w & 0xffu;
-        }
+        RT_BOX_STEP();  // Aabb::hit, aabb.rs:16-27, packed: per axis (t0, t1) = ((min, max) - o) * inv
+#if RT_BOX_UNROLL >= 2
+        RT_BOX_STEP();  // lanes that left the BOX state sit this one out; the schedule check runs every other step
+#endif
         n_now = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op == OP_BOX));
         if (COUNT) n_box_lanes += n_now;
       } while (n_now > floor_lanes);
@@ -507,6 +514,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
       atomicAdd(&counters[20], (unsigned long long)n_end), atomicAdd(&counters[21], (unsigned long long)n_end_lanes);
     }
   }
+#undef RT_BOX_STEP
 #undef RT_FETCH_LO
 #undef RT_FETCH_HI
 #undef RT_FETCH_MAT
