@@ -27,7 +27,7 @@ namespace rtg {
 
 constexpr uint32_t POOL = 192;           // path slots per wave: 64 in lanes + 128 waiting, so one wait list always holds >= 64
 constexpr uint32_t POOL_FIELDS = 20;     // dwords per slot (SoA: field f of slot j at [f * POOL + j])
-constexpr uint32_t WORK_BLOCK = 2048;    // work items a wave reserves per global atomic
+constexpr uint32_t WORK_BLOCK = 256;     // work items a wave reserves per global atomic (2048 cost 20 % on C2: ~6 blocks per wave = a coarse tail)
 constexpr uint32_t SLOT_NEED_PIXEL = 0xfffffffeu;  // best_pc marker: slot holds no ray yet
 constexpr uint32_t SLOT_ENDED = 0xfffffffdu;       // best_pc marker: path ended in a SCATTER pass, colour parked in accum
 

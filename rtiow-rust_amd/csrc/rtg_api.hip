@@ -163,6 +163,13 @@ struct rtg_scene {
   int block_threads = 512, wg_per_cu = 0;  // 0 = ask the occupancy API
 };
 
+// The per-sample colour scratch may take up to half of the free HBM (288 GB per MI355X).
+static uint64_t scratch_cap() {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 16ull << 30;
+  return (uint64_t)free_b / 2;
+}
+
 static uint64_t owned_pixels(const DevParams& d);
 
 // Lean scenes: persistent wavefronts pulling pixels from a work counter (rt_persistent.h).
@@ -216,7 +223,7 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
     if (s->force_chunks > 0) n_chunks = (uint64_t)s->force_chunks;
     if (n_chunks > d.ns) n_chunks = d.ns;
     const uint64_t need = pix_work * d.ns * 3 * sizeof(float);
-    if (n_chunks > 1 && need <= (16ull << 30) && pix_work * n_chunks <= 0xfffffffeull) {
+    if (n_chunks > 1 && pix_work * n_chunks <= 0xfffffffeull && (need <= s->scratch_bytes || need <= scratch_cap())) {
       if (need > s->scratch_bytes) {
         if (s->d_scratch) (void)hipFree(s->d_scratch);
         s->d_scratch = nullptr, s->scratch_bytes = 0;
@@ -297,7 +304,7 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
   const uint64_t pix_work = (uint64_t)owned * d.tile_w * d.tile_h;
   const uint64_t scratch_need = pix_work * d.ns * 3 * sizeof(float);
   const uint64_t total_work = pix_work * d.ns;
-  if (scratch_need > (16ull << 30) || total_work > 0xfffffffeull) return hipErrorNotSupported;
+  if (total_work > 0xfffffffeull || (scratch_need > s->scratch_bytes && scratch_need > scratch_cap())) return hipErrorNotSupported;
   if (pix_work == 0) return hipSuccess;
   const int bt = s->block_threads;
   const uint32_t waves = (uint32_t)bt / 64;
@@ -338,25 +345,22 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
 }
 
 template <bool COUNT>
-static void launch_render(rtg_scene* s, const DevCamera& cam, const DevParams& d, float* d_out,
-                          hipStream_t stream) {
+static hipError_t launch_render(rtg_scene* s, const DevCamera& cam, const DevParams& d, float* d_out,
+                                hipStream_t stream) {
   if (s->features != 0 && s->kernel_version >= 3 && d.nx <= 0xffffu && d.ny <= 0xffffu) {
-    if (launch_full_pool<COUNT>(s, cam, d, d_out, stream) != hipErrorNotSupported) return;
+    hipError_t e = launch_full_pool<COUNT>(s, cam, d, d_out, stream);
+    if (e != hipErrorNotSupported) return e;
   }
-  if (s->features == 0 && s->kernel_version >= 3 && d.nx <= 0xffffu && d.ny <= 0xffffu) {
-    (void)launch_pool<COUNT>(s, cam, d, d_out, stream);
-    return;
-  }
-  if (s->features == 0 && s->kernel_version >= 2) {
-    (void)launch_persistent<COUNT>(s, cam, d, d_out, stream);
-    return;
-  }
+  if (s->features == 0 && s->kernel_version >= 3 && d.nx <= 0xffffu && d.ny <= 0xffffu)
+    return launch_pool<COUNT>(s, cam, d, d_out, stream);
+  if (s->features == 0 && s->kernel_version >= 2) return launch_persistent<COUNT>(s, cam, d, d_out, stream);
   uint32_t nbx = (d.nx + 15) / 16, nby = (d.ny + 15) / 16;
   dim3 grid(nbx * nby), block(256);
   if (s->features == 0)
     hipLaunchKernelGGL((render_kernel<0u, COUNT>), grid, block, 0, stream, s->dev, cam, d, d_out, s->d_counters);
   else
     hipLaunchKernelGGL((render_kernel<FEAT_ALL, COUNT>), grid, block, 0, stream, s->dev, cam, d, d_out, s->d_counters);
+  return hipGetLastError();
 }
 
 template <typename T>
@@ -749,9 +753,7 @@ int rtg_par_cast_device(rtg_scene* s, const rtg_camera* camera, const rtg_params
     HIP_TRY(hipMemsetAsync(s->d_counters + 8, 0, 16 * sizeof(unsigned long long), stream));
   }
   if (stats) HIP_TRY(hipEventRecord(s->ev0, stream));
-  if (count) launch_render<true>(s, cam, d, d_out, stream);
-  else launch_render<false>(s, cam, d, d_out, stream);
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(count ? launch_render<true>(s, cam, d, d_out, stream) : launch_render<false>(s, cam, d, d_out, stream));
   if (stats) {
     HIP_TRY(hipEventRecord(s->ev1, stream));
     HIP_TRY(hipEventSynchronize(s->ev1));
