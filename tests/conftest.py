@@ -18,7 +18,10 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def pkg():
-    return graft.load_package()
+    p = graft.load_package()
+    if not os.path.exists(p.LIB_PATH):   # fresh checkout: compile the HIP library (hipcc cross-compiles anywhere)
+        graft.build()
+    return p
 
 
 @pytest.fixture(scope="session")

@@ -27,6 +27,21 @@ def _checker_scale(pkg, b, nx, ny):
     return world, cam, exp
 
 
+def _big_lean(pkg, b, nx, ny):
+    """3000 spheres under one Bvh: a lean scene whose flat program (8999 records = 288 KB) does NOT fit
+    LDS, so the ray-pool kernel runs its global-memory-program variant."""
+    S = pkg.scenes
+    rng = pkg.small_rng.SmallRng(42)
+    objs = [b.translate(S.v(0.0, -1000.0, 0.0), b.sphere(1000.0, b.lambertian(b.constant(S.vfrom(0.5)))))]
+    mats = [b.lambertian(b.constant(S.v(0.7, 0.3, 0.2))), b.metal(S.v(0.8, 0.8, 0.9), 0.1), b.dielectric(1.5)]
+    for i in range(2998):
+        c = S.f32(24.0) * rng.gen_vec3() - S.f32(12.0)
+        objs.append(b.translate(S.v(c[0], S.f32(0.1) + S.f32(3.0) * rng.gen_f32(), c[2]), b.sphere(0.1, mats[i % 3])))
+    objs.append(b.flip_normals(b.sphere(10000.0, b.diffuse_light(b.constant(S.v(0.7, 0.8, 1.0)), 1.0))))
+    cam = b.be.camera_look(S.v(13, 2, 3), S.v(0, 0, 0), S.v(0.0, 1.0, 0.0), 20.0, float(S.f32(nx) / S.f32(ny)), 0.1, 10.0)
+    return [b.bvh(objs, (0.0, 1.0))], cam, (0.0, 1.0)
+
+
 CASES = {
     # name: (builder fn (pkg, b, nx, ny) -> (world, cam, exposure), nx, ny, ns)
     "cornell": (lambda pkg, b, nx, ny: pkg.scenes.cornell_box_scene(b, nx, ny), 32, 32, 16),
@@ -42,6 +57,7 @@ CASES = {
     "simple_light": (lambda pkg, b, nx, ny: pkg.scenes.simple_light_scene(
         b, nx, ny, pkg.small_rng.SmallRng(0xDEADBEEF), spheres=200), 24, 24, 4),
     "checker_scale": (_checker_scale, 32, 32, 8),
+    "big_lean": (_big_lean, 40, 24, 6),
 }
 
 
