@@ -36,12 +36,23 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(pkg, nx, ny, target_seconds=12.0, max_spp=50):
+WORKLOADS = {
+    # name: (scene builder(pkg, b, nx, ny) -> (world, camera, exposure), nx, ny, spp per GPU, description)
+    "book1": (lambda pkg, b, nx, ny: pkg.scenes.random_scene(b, nx, ny), 1200, 800, 50,
+              "SmallRng(0xDEADBEEF) book-1 random spheres under bvh::from_scene + sky-dome emitter (SURVEY.md 8d)"),
+    "book2": (lambda pkg, b, nx, ny: pkg.scenes.book_final_scene(b, nx, ny, pkg.small_rng.SmallRng(0xDEADBEEF)), 800, 800, 1000,
+              "book_final_scene (src/main.rs:161-319), list world (USE_BVH = false), SmallRng(0xDEADBEEF) construction"),
+    "cornell": (lambda pkg, b, nx, ny: pkg.scenes.cornell_box_scene(b, nx, ny), 300, 300, 100,
+                "cornell_box_scene (src/main.rs:11-30): Cornell box + two prisms, list world"),
+}
+
+
+def cpu_baseline(pkg, build_scene, nx, ny, target_seconds=12.0, max_spp=50):
     """TEST-INFRASTRUCTURE leg: time the CPU oracle (C++ restatement, row-parallel like lib.rs:326-330)
     on all host cores, on a bounded sample of the same workload (same scene/seed, reduced spp)."""
     ora = graft.load_oracle()
     b = ora.builder()
-    world, cam, _ = pkg.scenes.random_scene(b, nx, ny)
+    world, cam, _ = build_scene(pkg, b, nx, ny)
     scene = b.scene(world)
     cores = usable_cores()
     t0 = time.perf_counter()
@@ -52,7 +63,7 @@ def cpu_baseline(pkg, nx, ny, target_seconds=12.0, max_spp=50):
     scene.par_cast(cam, nx, ny, spp, threads=cores)
     dt = time.perf_counter() - t0
     return {"value": nx * ny * spp / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "book-1 %dx%d at %d spp (same scene and seed), oracle par_cast on %d threads, %.1f s"
+            "sample": "%dx%d at %d spp (same scene and seed), oracle par_cast on %d threads, %.1f s"
                       % (nx, ny, spp, cores, dt)}
 
 
@@ -61,9 +72,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--nx", type=int, default=1200)
-    ap.add_argument("--ny", type=int, default=800)
-    ap.add_argument("--spp", type=int, default=0, help="samples per pixel (default 50 * gpus)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="book1",
+                    help="book1 = BASELINE.json's metric workload (default); book2 / cornell = configs[3] / configs[0]")
+    ap.add_argument("--nx", type=int, default=0)
+    ap.add_argument("--ny", type=int, default=0)
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel (default: the workload's spp * gpus)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xDEADBEEF)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true",
@@ -95,13 +108,15 @@ def main():
 
     pkg = graft.load_package()
     gpu = pkg.load()
-    nx, ny = args.nx, args.ny
-    spp = args.spp or 50 * world
+    build_scene, wnx, wny, wspp, wdesc = WORKLOADS[args.workload]
+    nx, ny = args.nx or wnx, args.ny or wny
+    spp = args.spp or wspp * world
 
     b = gpu.builder()
-    objs, cam, _ = pkg.scenes.random_scene(b, nx, ny)
+    objs, cam, _ = build_scene(pkg, b, nx, ny)
     scene = b.scene(objs, device=dev_index)
     info = scene.info()
+    info_lean = args.workload == "book1"
 
     fb = torch.zeros((ny, nx, 3), dtype=torch.float32, device=dev)
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -170,12 +185,13 @@ def main():
             # tools/summarize_pmc.py); counters cannot be read from inside the process
             try:
                 tj = json.load(open(tpath))
-                if tj.get("workload") == "book1_%dx%dx%d" % (nx, ny, spp):
+                if tj.get("workload") == "%s_%dx%dx%d" % (args.workload, nx, ny, spp):
                     traffic = tj["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
         line = {
-            "metric": "Msamples/s (pixels*spp/s), book-1 random-spheres %dx%d" % (nx, ny),
+            "metric": "Msamples/s (pixels*spp/s), %s %dx%d" % (
+                {"book1": "book-1 random-spheres", "book2": "book-2 final scene", "cornell": "Cornell box"}[args.workload], nx, ny),
             "value": total_samples / (elapsed / args.steps) / 1e6,
             "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -183,19 +199,20 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "book1_random_spheres_%dx%dx%dspp" % (nx, ny, spp),
-                "scene": "SmallRng(0xDEADBEEF) book-1 random spheres under bvh::from_scene + sky-dome emitter "
-                         "(SURVEY.md 8d), %d flat-program instructions, %d materials, %d B in HBM"
-                         % (info["instructions"], info["materials"], info["hbm_bytes"]),
+                "workload": "%s_%dx%dx%dspp" % ({"book1": "book1_random_spheres", "book2": "book2_final_scene",
+                                                 "cornell": "cornell_box_with_boxes"}[args.workload], nx, ny, spp),
+                "scene": "%s, %d flat-program instructions, %d materials, %d B in HBM"
+                         % (wdesc, info["instructions"], info["materials"], info["hbm_bytes"]),
                 "max_bounces": 50, "seed": hex(args.seed),
                 "sharding": "none" if world == 1 else
-                            "interleaved 16x16 pixel tiles (tile %% %d == rank), spp = 50*N; RCCL reduce(sum) of the "
-                            "float3 framebuffer to rank 0" % world,
+                            "interleaved 16x16 pixel tiles (tile %% %d == rank), spp = %d*N; RCCL reduce(sum) of the "
+                            "float3 framebuffer to rank 0" % (world, wspp),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "rtg::render_lean_pool (+ rtg::fold_samples_kernel, <1%): HIP events around both on the launch stream",
+                "kernel": ("rtg::render_lean_pool" if info_lean else "rtg::render_full_pool") +
+                          " (+ rtg::fold_samples_kernel, <1%): HIP events around both on the launch stream",
                 "kernel_ms_avg": avg_kernel_ms,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "counters_per_launch": {k: cst[k] for k in ("aabb_tests", "prim_tests", "shaded_hits", "rays", "draws")},
@@ -204,7 +221,7 @@ def main():
         if verified is not None:
             line["verified_bit_exact_vs_unsharded"] = verified
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(pkg, nx, ny)
+            line["cpu_baseline"] = cpu_baseline(pkg, build_scene, nx, ny)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
