@@ -211,9 +211,10 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
   uint32_t tiles = tiles_x * tiles_y;
   uint32_t owned = tiles > d.rank ? (tiles - d.rank + d.nranks - 1) / d.nranks : 0;
   const uint64_t pix_work = (uint64_t)owned * d.tile_w * d.tile_h;
+  if (pix_work == 0) return hipSuccess;  // this rank owns no tile
   const int bt = s->block_threads;
   const uint32_t waves = (uint32_t)bt / 64;
-  // chunk mode when the rank owns too few pixels to keep every path slot of the chip busy
+  // sample-chunk mode (see rt_pool.h)
   ChunkMode cm{nullptr, d.ns, 1, (uint32_t)pix_work};
   {
     // Default: one sample per work item.  Work items are then ~100x more numerous than path slots, so

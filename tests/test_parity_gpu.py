@@ -265,3 +265,25 @@ def test_bench_multi_rank_path_on_one_gpu(tmp_path):
     assert line["n_gpus"] == 2 and line["verified_bit_exact_vs_unsharded"] is True
     assert line["config"]["workload"].endswith("x100spp") and line["scaling"] == "weak"
     assert line["roofline"]["bound"] == "hbm" and line["value"] > 0
+
+
+def test_degenerate_inputs(pkg, gpu, oracle):
+    """Empty world (lib.rs:100: every ray misses -> black), ranks that own no tile, 1x1 images, ns = 1."""
+    S = pkg.scenes
+    b = gpu.builder()
+    cam = gpu.camera_look(S.v(0, 0, -5), S.v(0, 0, 0), S.v(0, 1, 0), 40.0, 1.0, 0.0, 10.0)
+    img = b.scene([]).par_cast(cam, 20, 12, 3)
+    assert img.shape == (12, 20, 3) and (img == 0).all()
+    # more ranks than tiles: ranks 2.. own nothing and must leave the canvas untouched
+    sg, cam_g, _, _, _ = build_case(pkg, gpu, "book1", 24, 16)     # 2 tiles of 16x16
+    so, cam_o, _, _, _ = build_case(pkg, oracle, "book1", 24, 16)
+    ref = so.par_cast(cam_o, 24, 16, 2)
+    acc = np.zeros_like(ref)
+    for r in range(5):
+        canvas = np.full_like(ref, 0.0)
+        acc += sg.par_cast(cam_g, 24, 16, 2, rank=r, nranks=5, out=canvas)
+    assert_bit_equal(acc, ref, "5 ranks, 2 tiles")
+    for name in ("book1", "cornell", "book2"):
+        sg, cam_g, _, _, _ = build_case(pkg, gpu, name, 1, 1)
+        so, cam_o, _, _, _ = build_case(pkg, oracle, name, 1, 1)
+        assert_bit_equal(sg.par_cast(cam_g, 1, 1, 1), so.par_cast(cam_o, 1, 1, 1), name + " 1x1x1")
