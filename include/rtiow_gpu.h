@@ -149,6 +149,14 @@ int rtg_par_cast(rtg_scene* s, const rtg_camera* camera, const rtg_params* param
 int rtg_par_cast_device(rtg_scene* s, const rtg_camera* camera, const rtg_params* params,
                         float* d_out_rgb, void* hip_stream, rtg_stats* stats_or_null);
 
+/* ---- output stage -------------------------------------------------------------------------- */
+/* print_ppm's per-channel quantisation (lib.rs:348-356): sqrt gamma, `(255.99 * x) as i32` (saturating,
+ * NaN -> 0), clamped to 0..=255.  n floats in, n bytes out; both HOST pointers, computed on `device`.
+ * The ASCII P3 writer itself stays on the host (rtiow-rust_amd/ppm.py, host/rtiow.hpp). */
+int rtg_tonemap(int device, size_t n, const float* rgb, uint8_t* out_u8);
+/* Same on DEVICE pointers, enqueued on `hip_stream`. */
+int rtg_tonemap_device(int device, size_t n, const float* d_rgb, uint8_t* d_out_u8, void* hip_stream);
+
 /* ---- probes used by the parity tests (not part of the reference surface) ------------------ */
 /* One hit_top() (lib.rs:33-49) per ray. rays: n x 7 floats (origin, direction, time).
  * out: n x 8 floats (hit?1:0, t, p.xyz, normal.xyz); out_material: n material handles.

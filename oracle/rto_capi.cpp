@@ -412,6 +412,16 @@ int rto_cast(rto_scene* s, const rto_camera* camera, uint32_t nx, uint32_t ny, u
   return 0;
 }
 
+// print_ppm's per-channel quantisation, lib.rs:348-356
+int rto_tonemap(int /*device*/, size_t n, const float* rgb, uint8_t* out) {
+  for (size_t i = 0; i < n; i++) {
+    float c = std::sqrt(rgb[i]);            // lib.rs:348
+    int32_t q = f32_as_i32(255.99f * c);    // lib.rs:351 `(255.99 * x) as i32`
+    out[i] = (uint8_t)std::min(255, std::max(0, q));  // .max(0).min(255)
+  }
+  return 0;
+}
+
 // ---- probes ---------------------------------------------------------------------------------
 int rto_debug_hit_top(rto_scene* s, size_t n, const float* rays, uint64_t seed, float t_near,
                       float* out, uint32_t* out_material) {

@@ -72,7 +72,7 @@ ABI_SYMBOLS = [
     "material_isotropic", "object_sphere", "object_rect", "object_flip_normals", "object_translate",
     "object_scale", "object_rotate_y", "object_and", "object_rect_prism", "object_linear_move",
     "object_constant_medium", "object_bvh", "camera_look", "scene_create", "scene_destroy",
-    "scene_info", "par_cast", "par_cast_device", "debug_hit_top", "debug_samples", "debug_math", "debug_flatten",
+    "scene_info", "par_cast", "par_cast_device", "debug_hit_top", "debug_samples", "debug_math", "debug_flatten", "tonemap", "tonemap_device",
 ]
 
 
@@ -119,6 +119,7 @@ class Backend:
         f("debug_samples", C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_size_t,
                                      c_u32p, c_u32p, c_u32p, c_f32p, c_u32p])
         f("debug_math", C.c_int, [C.c_int, C.c_int, C.c_size_t, c_f32p, c_f32p, c_f32p])
+        f("tonemap", C.c_int, [C.c_int, C.c_size_t, c_f32p, c_u8p])
 
     def _declare_render(self):
         f = self._fn
@@ -128,6 +129,7 @@ class Backend:
         f("par_cast_device", C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_void_p,
                                        C.c_void_p, C.POINTER(Stats)])
         f("debug_flatten", C.c_int, [C.c_void_p, c_u32p, C.c_size_t, c_u32p, c_u32p, c_u32p, C.c_size_t])
+        f("tonemap_device", C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p])
 
     def _fn(self, name, restype, argtypes):
         fn = getattr(self.lib, self.prefix + name)
@@ -162,6 +164,13 @@ class Backend:
         self.check(self._camera_look(_f3(look_from), _f3(look_at), _f3(up), fov, aspect, aperture,
                                      focus_dist, exposure[0], exposure[1], C.byref(cam)))
         return cam
+
+    def tonemap(self, img, device=0):
+        """print_ppm's sqrt-gamma + `(255.99 * x) as i32` clamp (lib.rs:348-356) -> uint8 array of img's shape."""
+        x = np.ascontiguousarray(img, dtype=np.float32)
+        out = np.empty(x.shape, dtype=np.uint8)
+        self.check(self._tonemap(device, x.size, x.ctypes.data_as(c_f32p), out.ctypes.data_as(c_u8p)))
+        return out
 
     def debug_math(self, op, x, y=None, device=0):
         x = np.ascontiguousarray(x, dtype=np.float32)

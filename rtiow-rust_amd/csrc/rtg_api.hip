@@ -97,6 +97,15 @@ __global__ void debug_samples_kernel(DevScene sc, DevCamera cam, DevParams P, ui
   out_info[4 * i] = bounces, out_info[4 * i + 1] = draws, out_info[4 * i + 2] = cnt.aabb, out_info[4 * i + 3] = cnt.prim;
 }
 
+// print_ppm's to_u8 (lib.rs:348-352): sqrt, * 255.99, `as i32` (saturating, NaN -> 0), clamp 0..=255
+__global__ void tonemap_kernel(size_t n, const float* __restrict__ rgb, uint8_t* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = 255.99f * __builtin_sqrtf(rgb[i]);
+  int32_t q = f32_as_i32(v);
+  out[i] = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
+}
+
 __global__ void debug_math_kernel(int op, size_t n, const float* in, const float* in2, float* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -862,6 +871,31 @@ int rtg_debug_samples(rtg_scene* s, const rtg_camera* camera, const rtg_params* 
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(out_rgb, drgb.p, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(out_info, dinfo.p, 4 * n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return RTG_OK;
+}
+
+int rtg_tonemap_device(int device, size_t n, const float* d_rgb, uint8_t* d_out, void* hip_stream) {
+  if (!d_rgb || !d_out) return fail(RTG_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(device));
+  if (n) hipLaunchKernelGGL(tonemap_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, n, d_rgb, d_out);
+  HIP_TRY(hipGetLastError());
+  return RTG_OK;
+}
+
+int rtg_tonemap(int device, size_t n, const float* rgb, uint8_t* out) {
+  if (!rgb || !out) return fail(RTG_ERR_INVALID, "null argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(RTG_ERR_DEVICE, "no HIP device");
+  HIP_TRY(hipSetDevice(device));
+  DevBuf<float> di;
+  DevBuf<uint8_t> dout;
+  HIP_TRY(di.alloc(n));
+  HIP_TRY(dout.alloc(n));
+  HIP_TRY(hipMemcpy(di.p, rgb, n * sizeof(float), hipMemcpyHostToDevice));
+  int rc = rtg_tonemap_device(device, n, di.p, dout.p, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, dout.p, n, hipMemcpyDeviceToHost));
   return RTG_OK;
 }
 

@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported(pkg):
 
 def test_oracle_mirrors_the_abi(pkg, oracle):
     for s in pkg.capi.ABI_SYMBOLS:
-        if s in ("device_count", "scene_info", "par_cast_device", "debug_flatten"):
+        if s in ("device_count", "scene_info", "par_cast_device", "debug_flatten", "tonemap_device"):
             continue  # device plumbing has no CPU counterpart
         assert hasattr(oracle.lib, "rto_" + s), s
 

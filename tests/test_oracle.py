@@ -200,3 +200,14 @@ def test_oracle_error_codes(pkg, oracle):
     assert "zero objects" in str(e.value)   # bvh.rs:60
     with pytest.raises(pkg.RtError):
         b.perlin(1.0)                        # tables not set
+
+
+def test_print_ppm_quantisation(pkg, oracle):
+    """lib.rs:348-356: sqrt gamma, (255.99 * x) as i32 with Rust's saturating cast, clamp to 0..=255."""
+    x = np.array([0.0, 1.0, 0.25, 4.0, -1.0, np.nan, np.inf, 1e-12, 0.999, 0.5], dtype=np.float32)
+    q = oracle.tonemap(x)
+    assert q.tolist() == [0, 255, 127, 255, 0, 0, 255, 0, 255, 181]
+    rs = np.random.RandomState(1)
+    img = rs.rand(16, 8, 3).astype(np.float32) * 1.3
+    assert np.array_equal(oracle.tonemap(img), pkg.ppm.to_u8(img).astype(np.uint8))
+    assert pkg.ppm.format_ppm(img).startswith("P3\n8 16\n255\n")

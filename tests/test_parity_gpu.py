@@ -287,3 +287,15 @@ def test_degenerate_inputs(pkg, gpu, oracle):
         sg, cam_g, _, _, _ = build_case(pkg, gpu, name, 1, 1)
         so, cam_o, _, _, _ = build_case(pkg, oracle, name, 1, 1)
         assert_bit_equal(sg.par_cast(cam_g, 1, 1, 1), so.par_cast(cam_o, 1, 1, 1), name + " 1x1x1")
+
+
+def test_output_stage_tonemap(pkg, gpu, oracle):
+    """print_ppm's quantisation as a GPU kernel, byte-exact against the oracle."""
+    rs = np.random.RandomState(5)
+    bits32 = rs.randint(0, 2 ** 32, size=1 << 18, dtype=np.uint64).astype(np.uint32).view(np.float32)  # every class
+    unit = (rs.rand(1 << 18) * 1.5).astype(np.float32)
+    for x in (bits32, unit):
+        assert np.array_equal(gpu.tonemap(x), oracle.tonemap(x))
+    sg, cam, nx, ny, ns = build_case(pkg, gpu, "cornell")
+    img = sg.par_cast(cam, nx, ny, ns)
+    assert np.array_equal(gpu.tonemap(img), pkg.ppm.to_u8(img).astype(np.uint8))
