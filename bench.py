@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="book1",
                     help="book1 = BASELINE.json's metric workload (default); book2 / cornell = configs[3] / configs[0]")
+    ap.add_argument("--bvh", choices=["reference", "sah"], default="reference",
+                    help="book1 only: 'reference' = Bvh::new's median split (bvh.rs:22-81, the parity mode and the "
+                         "default); 'sah' = the surface-area-heuristic builder (SURVEY.md 8 f2: same image, fewer Aabb tests)")
     ap.add_argument("--nx", type=int, default=0)
     ap.add_argument("--ny", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel (default: the workload's spp * gpus)")
@@ -109,6 +112,9 @@ def main():
     pkg = graft.load_package()
     gpu = pkg.load()
     build_scene, wnx, wny, wspp, wdesc = WORKLOADS[args.workload]
+    if args.workload == "book1" and args.bvh == "sah":
+        build_scene = lambda pkg, b, nx, ny: pkg.scenes.random_scene(b, nx, ny, use_bvh="sah")  # noqa: E731
+        wdesc = wdesc.replace("bvh::from_scene", "a SAH-built Bvh (non-reference tree shape)")
     nx, ny = args.nx or wnx, args.ny or wny
     spp = args.spp or wspp * world
 

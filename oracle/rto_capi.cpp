@@ -266,6 +266,22 @@ rto_id rto_object_bvh(rto_builder* b, const rto_id* objects, size_t n, float e0,
   }
 }
 
+rto_id rto_object_bvh_sah(rto_builder* b, const rto_id* objects, size_t n, float e0, float e1) {
+  std::vector<ObjectPtr> objs;
+  for (size_t i = 0; i < n; i++) {
+    auto o = obj(b, objects[i]);
+    if (!o) return fail(-1, "bad object"), RTO_INVALID_ID;
+    objs.push_back(o);
+  }
+  try {
+    std::shared_ptr<Bvh> bvh = Bvh::build_sah(std::move(objs), Range{e0, e1});
+    return push_obj(b, bvh);
+  } catch (const std::exception& e) {
+    fail(n == 0 ? -2 : -3, e.what());
+    return RTO_INVALID_ID;
+  }
+}
+
 int rto_camera_look(const float from[3], const float at[3], const float up[3], float fov,
                     float aspect, float aperture, float focus_dist, float e0, float e1,
                     rto_camera* out) {

@@ -474,6 +474,60 @@ struct Bvh final : Object {
     return node;
   }
 
+  // NOT IN THE REFERENCE ("next"): surface-area-heuristic builder over the same node
+  // type.  Full sweep on each axis over centroid-sorted objects; cost = SA(left)*n_left + SA(right)*n_right;
+  // ties keep the lower axis / earlier split; stable sorts.  One object per leaf like Bvh::new, so the
+  // traversal code (hit) is unchanged; only the tree shape differs.
+  static float half_area(const Aabb& b) {
+    Vec3 e = b.max - b.min;
+    return (e.x * e.y + e.y * e.z) + e.z * e.x;
+  }
+  static std::unique_ptr<Bvh> build_sah(std::vector<ObjectPtr> objs, Range exposure) {
+    if (objs.empty()) throw std::runtime_error("Can't create a BVH from zero objects.");
+    auto node = std::make_unique<Bvh>();
+    if (objs.size() == 1) {
+      node->bbox = objs[0]->bounding_box(exposure);
+      node->size = 1;
+      node->leaf = objs[0];
+      return node;
+    }
+    const size_t n = objs.size();
+    float best_cost = 0.f;
+    int best_axis = -1;
+    size_t best_split = 0;
+    std::vector<ObjectPtr> best_order;
+    for (int axis = 0; axis < 3; axis++) {
+      std::vector<std::pair<float, ObjectPtr>> keyed;
+      for (auto& o : objs) {
+        Aabb bb = o->bounding_box(exposure);
+        keyed.emplace_back(bb.min[axis] + bb.max[axis], o);
+      }
+      std::stable_sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+      std::vector<float> right_area(n);
+      Aabb acc = keyed[n - 1].second->bounding_box(exposure);
+      for (size_t i = n - 1; i >= 1; i--) {
+        acc = (i == n - 1) ? acc : acc.merge(keyed[i].second->bounding_box(exposure));
+        right_area[i] = half_area(acc);
+      }
+      Aabb left = keyed[0].second->bounding_box(exposure);
+      for (size_t i = 1; i < n; i++) {  // split: [0, i) | [i, n)
+        if (i > 1) left = left.merge(keyed[i - 1].second->bounding_box(exposure));
+        float cost = half_area(left) * (float)i + right_area[i] * (float)(n - i);
+        if (best_axis < 0 || cost < best_cost) {
+          best_cost = cost, best_axis = axis, best_split = i;
+          best_order.clear();
+          for (auto& k : keyed) best_order.push_back(k.second);
+        }
+      }
+    }
+    std::vector<ObjectPtr> l(best_order.begin(), best_order.begin() + best_split), r(best_order.begin() + best_split, best_order.end());
+    node->right = build_sah(std::move(r), exposure);
+    node->left = build_sah(std::move(l), exposure);
+    node->bbox = node->left->bbox.merge(node->right->bbox);
+    node->size = node->left->size + node->right->size;
+    return node;
+  }
+
   // bvh.rs:84-120
   bool hit(const Ray& ray, Range t_range, HitCtx& ctx, HitRecord* rec) const override {
     if (!bbox.hit(ray, t_range, ctx.counters)) return false;

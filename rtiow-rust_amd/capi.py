@@ -71,7 +71,7 @@ ABI_SYMBOLS = [
     "material_lambertian", "material_metal", "material_dielectric", "material_diffuse_light",
     "material_isotropic", "object_sphere", "object_rect", "object_flip_normals", "object_translate",
     "object_scale", "object_rotate_y", "object_and", "object_rect_prism", "object_linear_move",
-    "object_constant_medium", "object_bvh", "camera_look", "scene_create", "scene_destroy",
+    "object_constant_medium", "object_bvh", "object_bvh_sah", "camera_look", "scene_create", "scene_destroy",
     "scene_info", "par_cast", "par_cast_device", "debug_hit_top", "debug_samples", "debug_math", "debug_flatten", "tonemap", "tonemap_device",
 ]
 
@@ -111,6 +111,7 @@ class Backend:
         f("object_linear_move", C.c_uint32, [C.c_void_p, C.c_uint32, c_f32p])
         f("object_constant_medium", C.c_uint32, [C.c_void_p, C.c_uint32, C.c_float, C.c_uint32])
         f("object_bvh", C.c_uint32, [C.c_void_p, c_u32p, C.c_size_t, C.c_float, C.c_float])
+        f("object_bvh_sah", C.c_uint32, [C.c_void_p, c_u32p, C.c_size_t, C.c_float, C.c_float])
         f("camera_look", C.c_int, [c_f32p, c_f32p, c_f32p] + [C.c_float] * 6 + [C.POINTER(Camera)])
         f("scene_create", C.c_int, [C.c_void_p, c_u32p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)])
         f("scene_destroy", None, [C.c_void_p])
@@ -284,6 +285,11 @@ class Builder:
         self.be.check(self.be._debug_flatten(self.h, arr, len(world), C.byref(n), C.byref(feat),
                                              words.ctypes.data_as(c_u32p), n.value))
         return words, feat.value
+
+    def bvh_sah(self, objs, exposure=(0.0, 1.0)):
+        """Not in the reference: SAH-built Bvh; same results up to exact-t ties, fewer box tests."""
+        arr = (C.c_uint32 * max(1, len(objs)))(*objs)
+        return self.be.check_id(self.be._object_bvh_sah(self.h, arr, len(objs), exposure[0], exposure[1]))
 
     def scene(self, world, device=0):
         """Flatten `world` (the `[Box<dyn Object>]` of lib.rs:33) once into device memory."""

@@ -572,6 +572,16 @@ rtg_id rtg_object_bvh(rtg_builder* b, const rtg_id* objects, size_t n, float e0,
   }
 }
 
+rtg_id rtg_object_bvh_sah(rtg_builder* b, const rtg_id* objects, size_t n, float e0, float e1) {
+  if (!b || (!objects && n)) return bad("null argument");
+  try {
+    return b->sb.add_bvh(objects, n, e0, e1, true);
+  } catch (const BuildError& e) {
+    fail(e.code, e.msg);
+    return RTG_INVALID_ID;
+  }
+}
+
 // ---- camera (camera.rs:18-50; host-side setup, tan from the platform libm) ---------------------
 int rtg_camera_look(const float from[3], const float at[3], const float up[3], float fov, float aspect,
                     float aperture, float focus_dist, float e0, float e1, rtg_camera* out) {

@@ -162,14 +162,72 @@ int32_t SceneBuilder::build_bvh(std::vector<uint32_t> objs, float e0, float e1) 
   return (int32_t)bvh_nodes.size() - 1;
 }
 
-uint32_t SceneBuilder::add_bvh(const uint32_t* objs, size_t n, float e0, float e1) {
+// NOT IN THE REFERENCE: surface-area-heuristic split instead of the widest-axis median.
+// Same node type and one object per leaf, so the flattened program and its traversal are unchanged; only
+// the tree shape differs (closest-hit results are invariant except at exact-t ties).  Full sweep on every
+// axis over centroid-sorted objects, cost = SA(left) * n_left + SA(right) * n_right, strict `<` keeps the
+// lower axis / earlier split on ties, stable sorts -- deterministic and mirrored by the test oracle.
+int32_t SceneBuilder::build_bvh_sah(std::vector<uint32_t> objs, float e0, float e1) {
+  auto half_area = [](const Box3& b) {
+    float ex = b.mx[0] - b.mn[0], ey = b.mx[1] - b.mn[1], ez = b.mx[2] - b.mn[2];
+    return (ex * ey + ey * ez) + ez * ex;
+  };
+  HostBvhNode node;
+  const size_t n = objs.size();
+  if (n == 1) {
+    node.box = bounding_box(objs[0], e0, e1);
+    node.leaf = objs[0];
+    bvh_nodes.push_back(node);
+    return (int32_t)bvh_nodes.size() - 1;
+  }
+  float best_cost = 0.f;
+  int best_axis = -1;
+  size_t best_split = 0;
+  std::vector<uint32_t> best_order;
+  for (int axis = 0; axis < 3; axis++) {
+    std::vector<std::pair<float, uint32_t>> keyed;
+    keyed.reserve(n);
+    for (uint32_t id : objs) {
+      Box3 bb = bounding_box(id, e0, e1);
+      float key = bb.mn[axis] + bb.mx[axis];
+      if (key != key) throw BuildError{-3, "Bvh (sah): NaN centroid"};
+      keyed.emplace_back(key, id);
+    }
+    std::stable_sort(keyed.begin(), keyed.end(),
+                     [](const std::pair<float, uint32_t>& p, const std::pair<float, uint32_t>& q) { return p.first < q.first; });
+    std::vector<float> right_area(n);
+    Box3 acc = bounding_box(keyed[n - 1].second, e0, e1);
+    for (size_t i = n - 1; i >= 1; i--) {
+      if (i != n - 1) acc = merge(acc, bounding_box(keyed[i].second, e0, e1));
+      right_area[i] = half_area(acc);
+    }
+    Box3 left = bounding_box(keyed[0].second, e0, e1);
+    for (size_t i = 1; i < n; i++) {  // split [0, i) | [i, n)
+      if (i > 1) left = merge(left, bounding_box(keyed[i - 1].second, e0, e1));
+      float cost = half_area(left) * (float)i + right_area[i] * (float)(n - i);
+      if (best_axis < 0 || cost < best_cost) {
+        best_cost = cost, best_axis = axis, best_split = i;
+        best_order.clear();
+        for (auto& k : keyed) best_order.push_back(k.second);
+      }
+    }
+  }
+  std::vector<uint32_t> l(best_order.begin(), best_order.begin() + best_split), r(best_order.begin() + best_split, best_order.end());
+  node.right = build_bvh_sah(std::move(r), e0, e1);
+  node.left = build_bvh_sah(std::move(l), e0, e1);
+  node.box = merge(bvh_nodes[node.left].box, bvh_nodes[node.right].box);
+  bvh_nodes.push_back(node);
+  return (int32_t)bvh_nodes.size() - 1;
+}
+
+uint32_t SceneBuilder::add_bvh(const uint32_t* objs, size_t n, float e0, float e1, bool sah) {
   if (n == 0) throw BuildError{-2, "Can't create a BVH from zero objects."};  // bvh.rs:60
   std::vector<uint32_t> v(objs, objs + n);
   for (uint32_t id : v)
     if (id >= objects.size()) throw BuildError{-1, "bvh: bad object handle"};
   HostObject o;
   o.kind = HostObject::BVH;
-  o.a = (uint32_t)build_bvh(std::move(v), e0, e1);
+  o.a = (uint32_t)(sah ? build_bvh_sah(std::move(v), e0, e1) : build_bvh(std::move(v), e0, e1));
   objects.push_back(o);
   return (uint32_t)objects.size() - 1;
 }

@@ -68,12 +68,13 @@ class SceneBuilder {
 
   // All return an id or throw BuildError.
   uint32_t add_object(const HostObject& o);
-  uint32_t add_bvh(const uint32_t* objs, size_t n, float e0, float e1);
+  uint32_t add_bvh(const uint32_t* objs, size_t n, float e0, float e1, bool sah = false);
   Box3 bounding_box(uint32_t obj, float e0, float e1) const;
   void flatten(const uint32_t* world, size_t n, FlatScene* out) const;
 
  private:
   int32_t build_bvh(std::vector<uint32_t> objs, float e0, float e1);
+  int32_t build_bvh_sah(std::vector<uint32_t> objs, float e0, float e1);
   void emit(uint32_t obj, bool under_bvh, bool under_and_in_bvh, int depth, FlatScene* out) const;
   void emit_bvh(int32_t node, int depth, FlatScene* out) const;
 };

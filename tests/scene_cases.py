@@ -58,6 +58,7 @@ CASES = {
         b, nx, ny, pkg.small_rng.SmallRng(0xDEADBEEF), spheres=200), 24, 24, 4),
     "checker_scale": (_checker_scale, 32, 32, 8),
     "big_lean": (_big_lean, 40, 24, 6),
+    "book1_sah": (lambda pkg, b, nx, ny: pkg.scenes.random_scene(b, nx, ny, use_bvh="sah"), 48, 32, 8),
 }
 
 

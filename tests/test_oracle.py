@@ -211,3 +211,14 @@ def test_print_ppm_quantisation(pkg, oracle):
     img = rs.rand(16, 8, 3).astype(np.float32) * 1.3
     assert np.array_equal(oracle.tonemap(img), pkg.ppm.to_u8(img).astype(np.uint8))
     assert pkg.ppm.format_ppm(img).startswith("P3\n8 16\n255\n")
+
+
+def test_sah_tree_gives_the_reference_image(pkg, oracle):
+    """a SAH-built Bvh changes the tree, not the closest hits (only exact-t ties could
+    differ): same image as Bvh::new's median tree, with fewer Aabb::hit calls."""
+    ref, cam, nx, ny, ns = build_case(pkg, oracle, "book1", 64, 40)
+    sah, cam2, _, _, _ = build_case(pkg, oracle, "book1_sah", 64, 40)
+    a, sa = ref.par_cast(cam, nx, ny, 6, stats=True)
+    b_, sb = sah.par_cast(cam2, nx, ny, 6, stats=True)
+    assert_bit_equal(a, b_, "sah vs median tree")
+    assert sb["rays"] == sa["rays"] and sb["aabb_tests"] < 0.75 * sa["aabb_tests"]
