@@ -47,7 +47,7 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(pkg, build_scene, nx, ny, target_seconds=12.0, max_spp=50):
+def cpu_baseline(pkg, build_scene, nx, ny, target_seconds=12.0, max_spp=1000):
     """TEST-INFRASTRUCTURE leg: time the CPU oracle (C++ restatement, row-parallel like lib.rs:326-330)
     on all host cores, on a bounded sample of the same workload (same scene/seed, reduced spp)."""
     ora = graft.load_oracle()
