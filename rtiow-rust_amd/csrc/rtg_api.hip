@@ -384,7 +384,7 @@ struct DevBuf {
 
 extern "C" {
 
-const char* rtg_version(void) { return "rtiow-rust_amd 0.1 (gfx950 HIP; flat-program megakernel)"; }
+const char* rtg_version(void) { return "rtiow-rust_amd 0.1 (gfx950 HIP; flat-program ray-pool kernels)"; }
 const char* rtg_last_error(void) { return g_err.c_str(); }
 
 int rtg_device_count(int* n) {

@@ -1,6 +1,6 @@
-// main.cpp -- the reference's src/main.rs, transliterated against rtiow.hpp (C++ mirror of the crate
+// crate_mirror_demo.cpp -- the reference's src/main.rs, transliterated against rtiow.hpp (C++ mirror of the crate
 // over the C ABI).  Scene bodies follow src/lib.rs:103-193 and src/main.rs:11-108 line for line.
-//   g++ -std=c++17 -O2 main.cpp -o rtiow_main -L../../csrc -lrtiow_gpu -Wl,-rpath,'$ORIGIN/../../csrc'
+//   g++ -std=c++17 -O2 crate_mirror_demo.cpp -o rtiow_main -L../../csrc -lrtiow_gpu -Wl,-rpath,'$ORIGIN/../../csrc'
 //   ./rtiow_main cornell 300 300 100 > out.ppm
 #include <chrono>
 #include <cstdio>

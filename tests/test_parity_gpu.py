@@ -200,7 +200,7 @@ def test_config_c4_book2_800x800(pkg, gpu, oracle, name):
 
 
 def test_cxx_crate_mirror_example(pkg, gpu, tmp_path):
-    """host/examples/main.cpp = the reference's src/main.rs transliterated against host/rtiow.hpp.
+    """host/examples/crate_mirror_demo.cpp = the reference's src/main.rs transliterated against host/rtiow.hpp.
     Its PPM (print_ppm, lib.rs:344-361) must equal the one made from the ctypes path's framebuffer."""
     import subprocess
     exe = os.path.join(os.path.dirname(GOLD), "..", "rtiow-rust_amd", "host", "examples", "rtiow_main")
