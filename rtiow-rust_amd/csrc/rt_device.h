@@ -50,7 +50,7 @@ __device__ const LogfEntry kLogfTable[128] = {
 
 // f32::ln (object.rs:562): table (128 intervals, OFF = 0x3f328000 puts 1.0 mid-interval with c = 1)
 // + degree-6 log1p polynomial, all in f64, one final rounding to f32.
-RT_DEV float rt_logf(float x) {
+__device__ __attribute__((noinline)) float rt_logf(float x) {  // rare (one call per medium evaluation): out of line
   uint32_t ix = __float_as_uint(x);
   if (ix == 0u || ix == 0x80000000u) return -__builtin_inff();
   if (ix >= 0x7f800000u) {

@@ -25,8 +25,9 @@ enum FullPoolField : uint32_t {
   FF_SAMPLE = 21, FF_XY = 22, FF_EVDRAWS = 23,
 };
 
-inline size_t full_pool_lds_bytes(uint32_t n_prog, uint32_t waves, bool stage_program) {
-  return (stage_program ? (size_t)n_prog * 32 : 0) + (size_t)waves * POOL * 2 * 4;
+// LDS = the first `window` program records (all of them when the program fits, 0 = none) + the lists
+inline size_t full_pool_lds_bytes(uint32_t window, uint32_t waves) {
+  return (size_t)window * 32 + (size_t)waves * POOL * 2 * 4;
 }
 
 // draw `idx` (0-based) of the stream (seed, pixel, sample, event): word idx%4 of Philox block idx/4
@@ -41,29 +42,34 @@ __device__ __attribute__((noinline)) float event_draw_f32(uint64_t seed, uint32_
   return (float)(u >> 8) * (1.0f / 16777216.0f);
 }
 
-template <bool USE_LDS, bool TEX, bool COUNT>
+// PROG: 0 = program fetched from global memory (L1/L2), 1 = whole program staged in LDS, 2 = an LDS
+// window over the first `window` records (depth-first order, so it holds whole leading subtrees: book-2's
+// 199 KB program keeps its floor Bvh and most top-level objects in LDS) and global memory for the rest.
+template <int PROG, bool TEX, bool COUNT>
 __global__ __launch_bounds__(512) void render_full_pool(DevScene sc, DevCamera cam, DevParams P, float* __restrict__ out,
                                                         uint32_t total_work, uint32_t* __restrict__ queue,
                                                         unsigned long long* counters, PoolTuning tune, ChunkMode cm,
-                                                        uint32_t* __restrict__ g_slots, float* __restrict__ g_stack) {
+                                                        uint32_t* __restrict__ g_slots, float* __restrict__ g_stack,
+                                                        uint32_t window) {
   // TEX = the scene references a checker / Perlin texture: only then is texture_eval (and its register
   // footprint) compiled in
   constexpr uint32_t FEAT = FEAT_XFORM | FEAT_MEDIUM | FEAT_RECT | (TEX ? FEAT_TEXTURE : 0u);
   extern __shared__ uint4 s_mem[];
-  const uint32_t n_prog = sc.n_prog;
-  const uint32_t staged = USE_LDS ? 2u * n_prog : 0u;  // uint4 units
-  const uint32_t hi_off = 16u * n_prog;
+  constexpr bool USE_LDS = PROG != 0;
+  const uint32_t staged = USE_LDS ? 2u * window : 0u;  // uint4 units; pc = 16 r, hi[] of the window at +16 window
+  const uint32_t win_bytes = 16u * window;
   if (USE_LDS) {
-    for (uint32_t i = threadIdx.x; i < n_prog; i += blockDim.x) {
+    for (uint32_t i = threadIdx.x; i < window; i += blockDim.x) {
       uint4 h = sc.hi[i];
       if ((h.w & 0xffu) == OP_BOX) h.z *= 16u;
       s_mem[i] = sc.lo[i];
-      s_mem[n_prog + i] = h;
+      s_mem[window + i] = h;
     }
   }
   const char* s_bytes = reinterpret_cast<const char*>(s_mem);
-#define RT_FETCH_LO(pc_) (USE_LDS ? *reinterpret_cast<const uint4*>(s_bytes + (pc_)) : sc.lo[(pc_) >> 4])
-#define RT_FETCH_HI(pc_) (USE_LDS ? *reinterpret_cast<const uint4*>(s_bytes + hi_off + (pc_)) : fetch_hi_global(sc, (pc_) >> 4))
+#define RT_IN_LDS(pc_) (PROG == 1 || (PROG == 2 && (pc_) < win_bytes))
+#define RT_FETCH_LO(pc_) (RT_IN_LDS(pc_) ? *reinterpret_cast<const uint4*>(s_bytes + (pc_)) : sc.lo[(pc_) >> 4])
+#define RT_FETCH_HI(pc_) (RT_IN_LDS(pc_) ? *reinterpret_cast<const uint4*>(s_bytes + win_bytes + (pc_)) : fetch_hi_global(sc, (pc_) >> 4))
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, n_waves = blockDim.x >> 6;
   const size_t gwave = (size_t)blockIdx.x * n_waves + wave;
   uint32_t* slot = g_slots + gwave * (POOL * FPOOL_FIELDS);
@@ -99,6 +105,7 @@ __global__ __launch_bounds__(512) void render_full_pool(DevScene sc, DevCamera c
   Counts cnt = {0, 0, 0, 0};
   uint32_t total_draws = 0;
   uint32_t n_box_it = 0, n_box_lanes = 0, n_slow_it = 0, n_slow_lanes = 0, n_shade = 0, n_shade_lanes = 0, n_refill = 0;
+  unsigned long long t_shade = 0, t_serv = 0, t_box = 0, t_slow = 0, t_mark = 0, t_mark2 = 0;  // COUNT: s_memtime shares
 
   for (;;) {
     uint32_t op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
@@ -107,6 +114,7 @@ __global__ __launch_bounds__(512) void render_full_pool(DevScene sc, DevCamera c
     const uint32_t n_busy = (uint32_t)__builtin_popcountll(m_box | m_slow);
     // ============================== SERVICE ======================================================
     if (64u - n_busy >= tune.refill_min || n_busy == 0) {
+      if (COUNT) t_mark = RT_TICK();
       {  // (1) finish
         const bool fin = have_ray && op == OP_END;
         const uint64_t m_fin = __builtin_amdgcn_ballot_w64(fin);
@@ -125,7 +133,7 @@ __global__ __launch_bounds__(512) void render_full_pool(DevScene sc, DevCamera c
       while (s_count >= 64u || (s_count > 0 && t_count == 0 && n_busy == 0)) {
         const uint32_t take = s_count < 64u ? s_count : 64u;
         s_count -= take;
-        if (COUNT) n_shade++, n_shade_lanes += take;
+        if (COUNT) n_shade++, n_shade_lanes += take, t_mark2 = RT_TICK();
         uint32_t st = ST_DEAD, j = 0;
         V3 so = mk(0.f, 0.f, 0.f), sd = so, strength = so, accum = so;
         float stime = 0.f;
@@ -136,6 +144,16 @@ __global__ __launch_bounds__(512) void render_full_pool(DevScene sc, DevCamera c
           if (hm == SLOT_NEED_PIXEL) {
             st = ST_NEED_PIXEL;
           } else {
+            // The texture value is fetched FIRST, while almost nothing of this pass is live: texture_eval
+            // (Perlin turbulence / checker) is an out-of-line call and everything live across it adds to
+            // the kernel's register count.
+            const V3 p = mk(SLOT_F(FF_P, j), SLOT_F(FF_P + 1, j), SLOT_F(FF_P + 2, j));
+            uint4 mlo = make_uint4(0, 0, 0, 0), mhi = make_uint4(0, 0, 0, 0);
+            V3 texval = mk(0.f, 0.f, 0.f);
+            if (hm != NO_HIT) {
+              mlo = sc.mat[2 * hm], mhi = sc.mat[2 * hm + 1];
+              texval = material_texture<FEAT>(sc, mlo, mhi, p);  // = albedo / emission colour for constant textures
+            }
             so = mk(SLOT_F(FF_O, j), SLOT_F(FF_O + 1, j), SLOT_F(FF_O + 2, j));
             sd = mk(SLOT_F(FF_D, j), SLOT_F(FF_D + 1, j), SLOT_F(FF_D + 2, j));
             stime = SLOT_F(FF_TIME, j);
@@ -153,22 +171,19 @@ __global__ __launch_bounds__(512) void render_full_pool(DevScene sc, DevCamera c
             V3 result = mk(0.f, 0.f, 0.f);
             if (hm != NO_HIT) {
               if (COUNT) cnt.shaded++;
-              const V3 p = mk(SLOT_F(FF_P, j), SLOT_F(FF_P + 1, j), SLOT_F(FF_P + 2, j));
               const V3 n = mk(SLOT_F(FF_N, j), SLOT_F(FF_N + 1, j), SLOT_F(FF_N + 2, j));
-              const uint4 mlo = sc.mat[2 * hm], mhi = sc.mat[2 * hm + 1];
               const uint32_t kind = mhi.w & 0xffu;
               const float param = u2f(mlo.w);
               V3 emitted = mk(0.f, 0.f, 0.f);
-              if (kind == MAT_DIFFUSE_LIGHT) emitted = smul(param, material_texture<FEAT>(sc, mlo, mhi, p));
+              if (kind == MAT_DIFFUSE_LIGHT) emitted = smul(param, texval);  // material.rs:120-128
               accum = vadd(accum, vmul(strength, emitted));
-              V3 nd = mk(0.f, 0.f, 0.f), att = mk(0.f, 0.f, 0.f);
+              V3 nd = mk(0.f, 0.f, 0.f), att = texval;  // Lambertian / Isotropic: albedo(p)
               bool scattered = true;
               V3 rs = mk(0.f, 0.f, 0.f);
               if (kind == MAT_LAMBERTIAN || kind == MAT_METAL || kind == MAT_ISOTROPIC) rs = in_unit_sphere(rng);
               if (kind == MAT_LAMBERTIAN) {
                 V3 target = vadd(vadd(p, n), rs);
                 nd = vsub(target, p);
-                att = material_texture<FEAT>(sc, mlo, mhi, p);
               } else if (kind == MAT_METAL) {
                 V3 refl = reflect(vunit(sd), n);
                 nd = vadd(refl, smul(param, rs));
@@ -201,7 +216,6 @@ __global__ __launch_bounds__(512) void render_full_pool(DevScene sc, DevCamera c
                 scattered = false;
               } else {  // Isotropic
                 nd = rs;
-                att = material_texture<FEAT>(sc, mlo, mhi, p);
               }
               result = accum;
               if (scattered) {
@@ -284,6 +298,7 @@ __global__ __launch_bounds__(512) void render_full_pool(DevScene sc, DevCamera c
         t_count += (uint32_t)__builtin_popcountll(m_live);
         n_dead += take - (uint32_t)__builtin_popcountll(m_live);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (COUNT) t_shade += RT_TICK() - t_mark2;
       }
       {  // (3) refill
         const uint64_t m_idle = __builtin_amdgcn_ballot_w64(!have_ray);
@@ -310,6 +325,7 @@ __global__ __launch_bounds__(512) void render_full_pool(DevScene sc, DevCamera c
           if (COUNT) n_refill++;
         }
       }
+      if (COUNT) t_serv += RT_TICK() - t_mark;
       if (n_dead == POOL) break;
       if (__builtin_amdgcn_ballot_w64(have_ray) == 0) continue;
       op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
@@ -321,6 +337,7 @@ __global__ __launch_bounds__(512) void render_full_pool(DevScene sc, DevCamera c
       const uint32_t n0 = (uint32_t)__builtin_popcountll(b_box);
       const uint32_t floor_lanes = n0 > tune.box_leave ? n0 - tune.box_leave : 0u;
       uint32_t n_now;
+      if (COUNT) t_mark = RT_TICK();
       do {
         if (COUNT) n_box_it++;
         if (op == OP_BOX) {  // Aabb::hit, aabb.rs:16-27 (1/d and its sign re-read: d changes under RotateY/Scale)
@@ -341,9 +358,10 @@ __global__ __launch_bounds__(512) void render_full_pool(DevScene sc, DevCamera c
         n_now = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op == OP_BOX));
         if (COUNT) n_box_lanes += n_now;
       } while (n_now > floor_lanes);
+      if (COUNT) t_box += RT_TICK() - t_mark;
     } else if (b_slow != 0) {
       // ---- slow pass: every parked lane executes ONE record ----
-      if (COUNT) n_slow_it++, n_slow_lanes += (uint32_t)__builtin_popcountll(b_slow);
+      if (COUNT) n_slow_it++, n_slow_lanes += (uint32_t)__builtin_popcountll(b_slow), t_mark = RT_TICK();
       if (op == OP_SPHERE) {  // Sphere::hit, object.rs:84-111 (+ fused Translate / FlipNormals)
         if (COUNT) cnt.prim++;
         const V3 off = mk(u2f(cur_lo.x), u2f(cur_lo.y), u2f(cur_lo.z));
@@ -436,6 +454,7 @@ __global__ __launch_bounds__(512) void render_full_pool(DevScene sc, DevCamera c
         pc += 32u;
       }
       if (op >= OP_SPHERE && op <= OP_MEDIUM) cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc);
+      if (COUNT) t_slow += RT_TICK() - t_mark;
     }
   }
   if (COUNT) {
@@ -450,8 +469,11 @@ __global__ __launch_bounds__(512) void render_full_pool(DevScene sc, DevCamera c
       atomicAdd(&sched[2], (unsigned long long)n_slow_it), atomicAdd(&sched[3], (unsigned long long)n_slow_lanes);
       atomicAdd(&sched[4], (unsigned long long)n_shade), atomicAdd(&sched[5], (unsigned long long)n_shade_lanes);
       atomicAdd(&sched[6], (unsigned long long)n_refill);
+      atomicAdd(&counters[16], t_shade), atomicAdd(&counters[17], t_serv - t_shade), atomicAdd(&counters[18], t_box),
+          atomicAdd(&counters[19], t_slow);
     }
   }
+#undef RT_IN_LDS
 #undef RT_FETCH_LO
 #undef RT_FETCH_HI
 #undef SLOT_U

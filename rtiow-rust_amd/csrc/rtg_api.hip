@@ -316,6 +316,7 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
   const uint64_t total_work = pix_work * d.ns;
   if (total_work > 0xfffffffeull || (scratch_need > s->scratch_bytes && scratch_need > scratch_cap())) return hipErrorNotSupported;
   if (pix_work == 0) return hipSuccess;
+  const bool tex = (s->features & FEAT_TEXTURE) != 0;
   const int bt = s->block_threads;
   const uint32_t waves = (uint32_t)bt / 64;
   hipError_t e = grow((void**)&s->d_scratch, &s->scratch_bytes, scratch_need);
@@ -324,11 +325,27 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
   uint32_t* queue = (uint32_t*)(s->d_counters + 7);
   e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
-  const bool use_lds = full_pool_lds_bytes(s->n_prog, waves, true) <= 72 * 1024;  // two workgroups per CU
-  const size_t lds = full_pool_lds_bytes(s->n_prog, waves, use_lds);
-  const bool tex = (s->features & FEAT_TEXTURE) != 0;
-  auto kernel = use_lds ? (tex ? render_full_pool<true, true, COUNT> : render_full_pool<true, false, COUNT>)
-                        : (tex ? render_full_pool<false, true, COUNT> : render_full_pool<false, false, COUNT>);
+  // Program placement.  The untextured variant fits 128 VGPRs (two 512-thread workgroups per CU): stage the
+  // program when it fits beside a second workgroup (72 KB each).  The textured variant needs ~145 VGPRs, so
+  // only one workgroup is resident per CU and it may use ~150 KB of LDS: whole program or a leading window.
+  const size_t list_bytes = full_pool_lds_bytes(0, waves);
+  const size_t budget = tex ? 150 * 1024 : 72 * 1024;
+  uint32_t window = s->n_prog;
+  int prog = 1;
+  if ((size_t)window * 32 + list_bytes > budget) {
+    if (tex) window = (uint32_t)((budget - list_bytes) / 32), prog = 2;
+    else window = 0, prog = 0;
+  }
+  if (const char* kv = getenv("RTG_WINDOW")) {
+    window = std::min<uint32_t>(s->n_prog, (uint32_t)atoi(kv));
+    prog = window == 0 ? 0 : (window == s->n_prog ? 1 : 2);
+  }
+  const size_t lds = full_pool_lds_bytes(window, waves);
+  void (*kernel)(DevScene, DevCamera, DevParams, float*, uint32_t, uint32_t*, unsigned long long*, PoolTuning, ChunkMode,
+                 uint32_t*, float*, uint32_t);
+  if (prog == 0) kernel = tex ? render_full_pool<0, true, COUNT> : render_full_pool<0, false, COUNT>;
+  else if (prog == 1) kernel = tex ? render_full_pool<1, true, COUNT> : render_full_pool<1, false, COUNT>;
+  else kernel = tex ? render_full_pool<2, true, COUNT> : render_full_pool<2, false, COUNT>;
   e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   int per_cu = s->wg_per_cu;
@@ -344,10 +361,10 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
   e = grow((void**)&s->d_stack, &s->stack_bytes, (size_t)grid * waves * MAX_XFORM_DEPTH * 6 * 64 * sizeof(float));
   if (e != hipSuccess) return e;
   if (getenv("RTG_VERBOSE"))
-    fprintf(stderr, "[rtg] full pool: grid %u x %d threads, %d WG/CU, lds %zu B (program staged: %d)\n", grid, bt, per_cu, lds,
-            (int)use_lds);
+    fprintf(stderr, "[rtg] full pool: grid %u x %d threads, %d WG/CU, lds %zu B (program window: %u of %u records)\n", grid, bt,
+            per_cu, lds, window, s->n_prog);
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(bt), lds, stream, s->dev, cam, d, d_out, (uint32_t)total_work, queue,
-                     s->d_counters, s->pool_tune, cm, s->d_slots, s->d_stack);
+                     s->d_counters, s->pool_tune, cm, s->d_slots, s->d_stack, window);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(fold_samples_kernel, dim3((uint32_t)((pix_work + 255) / 256)), dim3(256), 0, stream, d, cm, d_out);
