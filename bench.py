@@ -55,10 +55,11 @@ def cpu_baseline(pkg, build_scene, nx, ny, target_seconds=12.0, max_spp=1000):
     world, cam, _ = build_scene(pkg, b, nx, ny)
     scene = b.scene(world)
     cores = usable_cores()
+    scene.par_cast(cam, nx, ny, 1, threads=cores)   # warm the thread pool / page in the scene
     t0 = time.perf_counter()
-    scene.par_cast(cam, nx, ny, 1, threads=cores)
-    t1 = time.perf_counter() - t0
-    spp = int(max(1, min(max_spp, target_seconds / max(t1, 1e-3))))
+    scene.par_cast(cam, nx, ny, 4, threads=cores)
+    t1 = (time.perf_counter() - t0) / 4.0             # seconds per spp
+    spp = int(max(1, min(max_spp, target_seconds / max(t1, 1e-4))))
     t0 = time.perf_counter()
     scene.par_cast(cam, nx, ny, spp, threads=cores)
     dt = time.perf_counter() - t0
