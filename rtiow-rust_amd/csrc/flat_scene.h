@@ -14,7 +14,9 @@
 //   Translate/Scale/RotateY/LinearMove/FlipNormals over a subtree -> PUSH, subtree, POP
 //   Sphere, Translate{Sphere}, FlipNormals thereof -> one fused SPHERE record
 //   Rect<A>, FlipNormals(Rect<A>)                  -> one RECT record
-//   ConstantMedium{boundary = one primitive}       -> MEDIUM record followed by the boundary record
+//   ConstantMedium{boundary}                       -> MEDIUM{end} followed by the boundary's own stream (one fused
+//                                                     primitive record in every reference scene; any object graph without
+//                                                     a nested medium otherwise), skipped by the main walk
 //
 // Every instruction is 32 bytes = two 16-byte packets, stored as two SoA arrays of uint4
 // (`lo[i]`, `hi[i]`) so that a lane fetches an instruction with two 16-byte loads.
@@ -31,7 +33,7 @@ enum Op : uint32_t {
   OP_RECT = 3,    // lo = (k, r0.start, r0.end, r1.start) hi = (r1.end, -, material, op|flags)
   OP_PUSH = 4,    // lo = (a, b, c, -)                   hi = (-, -, matching_pop, op|kind)
   OP_POP = 5,     // lo = (a, b, c, -)                   hi = (-, -, matching_push, op|kind)
-  OP_MEDIUM = 6,  // lo = (density, -, -, -)             hi = (-, -, material, op|flags); boundary = next record
+  OP_MEDIUM = 6,  // lo = (density, -, -, -)             hi = (end_pc, -, material, op|flags); boundary = records (pc, end_pc)
 };
 
 // flag bits in hi.w above the 8-bit opcode
@@ -40,6 +42,7 @@ constexpr uint32_t F_FLIP = 1u << 9;        // SPHERE/RECT: normal = -normal (od
 constexpr uint32_t F_AXIS_SHIFT = 10;       // RECT: bits 10-11 = orthogonal axis (0/1/2)
 constexpr uint32_t F_UNDER_BVH = 1u << 12;  // MEDIUM: lives below a Bvh node (hit-merge rule of bvh.rs:104-112)
 constexpr uint32_t F_BVH_ROOT = 1u << 13;   // BOX: root of an outermost Bvh (a Bvh not nested below another Bvh)
+constexpr uint32_t F_GENERAL_BOUNDARY = 1u << 14;  // MEDIUM: the boundary is an object graph (several records), not one primitive
 constexpr uint32_t F_MATKIND_SHIFT = 16;    // SPHERE/RECT/MEDIUM: bits 16-18 = MatKind of the record's material (copy, for schedulers)
 constexpr uint32_t F_KIND_SHIFT = 8;        // PUSH/POP: bits 8-10 = XformKind
 
@@ -66,5 +69,6 @@ constexpr uint32_t FEAT_XFORM = 1u;    // PUSH/POP present
 constexpr uint32_t FEAT_MEDIUM = 2u;   // MEDIUM present
 constexpr uint32_t FEAT_RECT = 4u;     // RECT present
 constexpr uint32_t FEAT_TEXTURE = 8u;  // a non-constant texture is referenced
+constexpr uint32_t FEAT_BOUNDARY = 16u; // a ConstantMedium whose boundary is an object graph (nested boundary walk)
 
 }  // namespace rtg

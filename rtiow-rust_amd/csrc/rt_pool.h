@@ -96,6 +96,7 @@ RT_DEV bool hi_is_root(uint4 hi) { return (hi.w & F_BVH_ROOT) != 0u; }
 RT_DEV uint4 fetch_hi_global(const DevScene& sc, uint32_t idx) {  // byte-offset skip pointers, global-memory variant
   uint4 h = sc.hi[idx];
   if ((h.w & 0xffu) == OP_BOX) h.z *= 16u;
+  if ((h.w & 0xffu) == OP_MEDIUM) h.x *= 16u;  // end of the boundary's stream
   return h;
 }
 

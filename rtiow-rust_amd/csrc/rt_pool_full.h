@@ -62,6 +62,7 @@ __global__ __launch_bounds__(512) void render_full_pool(DevScene sc, DevCamera c
     for (uint32_t i = threadIdx.x; i < window; i += blockDim.x) {
       uint4 h = sc.hi[i];
       if ((h.w & 0xffu) == OP_BOX) h.z *= 16u;
+      if ((h.w & 0xffu) == OP_MEDIUM) h.x *= 16u;
       s_mem[i] = sc.lo[i];
       s_mem[window + i] = h;
     }
@@ -427,6 +428,8 @@ __global__ __launch_bounds__(512) void render_full_pool(DevScene sc, DevCamera c
         if (kind == XF_ROTATE_Y || kind == XF_SCALE) inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
         pc += 16u;
       } else if (op == OP_MEDIUM) {  // ConstantMedium::hit, object.rs:545-575
+        // (scenes whose medium boundary is an object graph -- F_GENERAL_BOUNDARY -- are routed to the
+        // baseline kernel by the host: the nested boundary walk would cost every scene ~20 VGPRs here)
         const uint4 blo = RT_FETCH_LO(pc + 16u), bhi = RT_FETCH_HI(pc + 16u);
         float t1, t2;
         if (COUNT) cnt.prim++;
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(512) void render_full_pool(DevScene sc, DevCamera c
             }
           }
         }
-        pc += 32u;
+        pc = cur_hi.x;  // first record after the boundary's stream
       }
       if (op >= OP_SPHERE && op <= OP_MEDIUM) cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc);
       if (COUNT) t_slow += RT_TICK() - t_mark;

@@ -93,6 +93,77 @@ RT_DEV bool prim_hit_t(uint4 lo, uint4 hi, V3 o, V3 d, float t0, float t1, float
                     u2f(hi.x), t0, t1, t);
 }
 
+// `boundary.hit(ray, t_lo..t_hi)` of ConstantMedium (object.rs:551-552) when the boundary is an object graph:
+// a nested walk over the boundary's own records [first, end) that only keeps the closest t.  Same
+// predicates and visiting order as hit_top; no hit record, no media.  Rare path -> out of line, program
+// read from global memory, private ray stack.
+template <bool COUNT>
+__device__ __attribute__((noinline)) bool boundary_hit_t(const DevScene& sc, uint32_t first, uint32_t end_pc, V3 o, V3 d,
+                                                         float time, float t_lo, float t_hi, float& t_out, Counts& cnt) {
+  V3 inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+  float best = t_hi;
+  bool any = false;
+  int depth = 0;
+  V3 so[MAX_XFORM_DEPTH], sd[MAX_XFORM_DEPTH];
+  uint32_t pc = first;
+  while (pc < end_pc) {
+    const uint4 hi = sc.hi[pc], lo = sc.lo[pc];
+    const uint32_t op = hi.w & 0xffu;
+    if (op == OP_BOX) {
+      if (COUNT) cnt.aabb++;
+      float t0x = (u2f(lo.x) - o.x) * inv.x, t1x = (u2f(lo.y) - o.x) * inv.x;
+      float t0y = (u2f(lo.z) - o.y) * inv.y, t1y = (u2f(lo.w) - o.y) * inv.y;
+      float t0z = (u2f(hi.x) - o.z) * inv.z, t1z = (u2f(hi.y) - o.z) * inv.z;
+      float ax = inv.x < 0.f ? t1x : t0x, bx = inv.x < 0.f ? t0x : t1x;
+      float ay = inv.y < 0.f ? t1y : t0y, by = inv.y < 0.f ? t0y : t1y;
+      float az = inv.z < 0.f ? t1z : t0z, bz = inv.z < 0.f ? t0z : t1z;
+      float start = rs_max(t_lo, rs_max(rs_max(ax, ay), az));
+      float fin = rs_min(best, rs_min(rs_min(bx, by), bz));
+      pc = (fin > start) ? pc + 1 : hi.z;
+    } else if (op == OP_SPHERE) {
+      if (COUNT) cnt.prim++;
+      V3 lo_o = o;
+      if (hi.w & F_TRANSLATE) lo_o = vsub(o, mk(u2f(lo.x), u2f(lo.y), u2f(lo.z)));
+      float t;
+      if (sphere_hit_t(lo_o, d, u2f(lo.w), t_lo, best, t)) best = t, any = true;
+      pc++;
+    } else if (op == OP_RECT) {
+      if (COUNT) cnt.prim++;
+      float t;
+      if (rect_hit_t(o, d, (hi.w >> F_AXIS_SHIFT) & 3u, u2f(lo.x), u2f(lo.y), u2f(lo.z), u2f(lo.w), u2f(hi.x), t_lo, best, t))
+        best = t, any = true;
+      pc++;
+    } else if (op == OP_PUSH) {
+      const uint32_t kind = (hi.w >> F_KIND_SHIFT) & 7u;
+      so[depth] = o, sd[depth] = d;
+      depth++;
+      const V3 a = mk(u2f(lo.x), u2f(lo.y), u2f(lo.z));
+      if (kind == XF_TRANSLATE) {
+        o = vsub(o, a);
+      } else if (kind == XF_ROTATE_Y) {
+        o = rot_y(o, -a.x, a.y), d = rot_y(d, -a.x, a.y);
+        inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+      } else if (kind == XF_SCALE) {
+        o = vdiv(o, a), d = vdiv(d, a);
+        inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+      } else if (kind == XF_MOVE) {
+        o = vsub(o, smul(time, a));
+      }
+      pc++;
+    } else if (op == OP_POP) {
+      const uint32_t kind = (hi.w >> F_KIND_SHIFT) & 7u;
+      depth--;
+      o = so[depth], d = sd[depth];
+      if (kind == XF_ROTATE_Y || kind == XF_SCALE) inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+      pc++;
+    } else {
+      pc++;
+    }
+  }
+  t_out = best;
+  return any;
+}
+
 // World::hit_top (lib.rs:33-55) over the flat program.  `best` plays `nearest` / the shrinking
 // t_range.end; t_range.start is always t_near.  Returns Some/None, fills `rec` (world space).
 template <uint32_t FEAT, bool COUNT>
@@ -196,12 +267,24 @@ RT_DEV bool hit_top(const DevScene& sc, V3 o, V3 d, float time, float t_near, Sa
       continue;
     }
     if ((FEAT & FEAT_MEDIUM) && op == OP_MEDIUM) {  // ConstantMedium::hit, object.rs:545-575
+      const bool general = (hi.w & F_GENERAL_BOUNDARY) != 0u;
       const uint4 blo = sc.lo[pc + 1], bhi = sc.hi[pc + 1];
       float t1, t2;
-      if (COUNT) cnt.prim++;
-      if (prim_hit_t(blo, bhi, o, d, -F32_MAX, F32_MAX, t1)) {
+      bool h1, h2 = false;
+      if (general) {
+        h1 = boundary_hit_t<COUNT>(sc, pc + 1, hi.x, o, d, time, -F32_MAX, F32_MAX, t1, cnt);
+      } else {
         if (COUNT) cnt.prim++;
-        if (prim_hit_t(blo, bhi, o, d, t1 + 0.0001f, F32_MAX, t2)) {
+        h1 = prim_hit_t(blo, bhi, o, d, -F32_MAX, F32_MAX, t1);
+      }
+      if (h1) {
+        if (general) {
+          h2 = boundary_hit_t<COUNT>(sc, pc + 1, hi.x, o, d, time, t1 + 0.0001f, F32_MAX, t2, cnt);
+        } else {
+          if (COUNT) cnt.prim++;
+          h2 = prim_hit_t(blo, bhi, o, d, t1 + 0.0001f, F32_MAX, t2);
+        }
+        if (h2) {
           t1 = rs_max(t1, t_near);
           t2 = rs_min(t2, best);
           if (!(t1 >= t2)) {
@@ -222,7 +305,7 @@ RT_DEV bool hit_top(const DevScene& sc, V3 o, V3 d, float time, float t_near, Sa
           }
         }
       }
-      pc += 2;
+      pc = hi.x;  // first record after the boundary's stream
       continue;
     }
     pc++;  // unreachable for well-formed programs

@@ -374,7 +374,7 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
 template <bool COUNT>
 static hipError_t launch_render(rtg_scene* s, const DevCamera& cam, const DevParams& d, float* d_out,
                                 hipStream_t stream) {
-  if (s->features != 0 && s->kernel_version >= 3 && d.nx <= 0xffffu && d.ny <= 0xffffu) {
+  if (s->features != 0 && !(s->features & FEAT_BOUNDARY) && s->kernel_version >= 3 && d.nx <= 0xffffu && d.ny <= 0xffffu) {
     hipError_t e = launch_full_pool<COUNT>(s, cam, d, d_out, stream);
     if (e != hipErrorNotSupported) return e;
   }

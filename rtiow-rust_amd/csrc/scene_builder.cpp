@@ -272,40 +272,49 @@ static bool fuse_primitive(const SceneBuilder& b, uint32_t id, FlatScene* out, b
   }
 }
 
-void SceneBuilder::emit_bvh(int32_t node_id, int depth, FlatScene* out) const {
+void SceneBuilder::emit_bvh(int32_t node_id, int depth, FlatScene* out, bool in_boundary) const {
   const HostBvhNode& n = bvh_nodes[node_id];
   size_t at = out->lo.size();
   push(out, n.box.mn[0], n.box.mx[0], n.box.mn[1], n.box.mx[1], fbits(n.box.mn[2]), fbits(n.box.mx[2]), 0, OP_BOX);
   if (n.leaf != kNone) {
-    emit(n.leaf, true, false, depth, out);
+    emit(n.leaf, true, false, depth, out, in_boundary);
   } else {
-    emit_bvh(n.left, depth, out);
-    emit_bvh(n.right, depth, out);
+    emit_bvh(n.left, depth, out, in_boundary);
+    emit_bvh(n.right, depth, out, in_boundary);
   }
   out->hi[at].w[2] = (uint32_t)out->lo.size();  // skip pointer: first instruction after the subtree
 }
 
-void SceneBuilder::emit(uint32_t id, bool under_bvh, bool and_in_bvh, int depth, FlatScene* out) const {
+void SceneBuilder::emit(uint32_t id, bool under_bvh, bool and_in_bvh, int depth, FlatScene* out, bool in_boundary) const {
   const HostObject& o = objects[id];
   if (fuse_primitive(*this, id, out, true)) return;
   switch (o.kind) {
     case HostObject::AND:
-      emit(o.a, under_bvh, under_bvh, depth, out);
-      emit(o.b, under_bvh, under_bvh, depth, out);
+      emit(o.a, under_bvh, under_bvh, depth, out, in_boundary);
+      emit(o.b, under_bvh, under_bvh, depth, out, in_boundary);
       return;
     case HostObject::BVH: {
       size_t root = out->lo.size();
-      emit_bvh((int32_t)o.a, depth, out);
+      emit_bvh((int32_t)o.a, depth, out, in_boundary);
       if (!under_bvh) out->hi[root].w[3] |= F_BVH_ROOT;
       return;
     }
     case HostObject::MEDIUM: {
       if (and_in_bvh)
         throw BuildError{-5, "ConstantMedium below an And below a Bvh is not expressible in the flat program"};
-      if (!fuse_primitive(*this, o.a, out, false))
-        throw BuildError{-5, "ConstantMedium boundary must be a Sphere / Translate{Sphere} / Rect (optionally FlipNormals)"};
-      push(out, o.f[0], 0, 0, 0, 0, 0, o.mat, OP_MEDIUM | (under_bvh ? F_UNDER_BVH : 0u));
-      fuse_primitive(*this, o.a, out, true);
+      if (in_boundary)
+        throw BuildError{-5, "a ConstantMedium inside another medium's boundary is not expressible in the flat program"};
+      {
+        const size_t at = out->lo.size();
+        const bool single = fuse_primitive(*this, o.a, out, false);
+        push(out, o.f[0], 0, 0, 0, 0, 0, o.mat,
+             OP_MEDIUM | (under_bvh ? F_UNDER_BVH : 0u) | (single ? 0u : F_GENERAL_BOUNDARY) | (materials[o.mat].kind << F_MATKIND_SHIFT));
+        // the boundary's own stream: evaluated twice per medium test by a nested walk (object.rs:551-552),
+        // skipped by the main walk.  It starts a fresh wrapper depth (its rays are saved on a private stack).
+        if (single) fuse_primitive(*this, o.a, out, true);
+        else emit(o.a, false, false, 0, out, true), out->features |= FEAT_BOUNDARY;
+        out->hi[at].w[0] = (uint32_t)out->lo.size();  // end_pc
+      }
       out->features |= FEAT_MEDIUM;
       return;
     }
@@ -326,7 +335,7 @@ void SceneBuilder::emit(uint32_t id, bool under_bvh, bool and_in_bvh, int depth,
   out->features |= FEAT_XFORM;
   size_t at = out->lo.size();
   push(out, o.f[0], o.f[1], o.f[2], 0, 0, 0, 0, OP_PUSH | (kind << F_KIND_SHIFT));
-  emit(o.a, under_bvh, and_in_bvh, depth + 1, out);
+  emit(o.a, under_bvh, and_in_bvh, depth + 1, out, in_boundary);
   out->hi[at].w[2] = (uint32_t)out->lo.size();
   push(out, o.f[0], o.f[1], o.f[2], 0, 0, 0, (uint32_t)at, OP_POP | (kind << F_KIND_SHIFT));
 }

@@ -75,8 +75,8 @@ class SceneBuilder {
  private:
   int32_t build_bvh(std::vector<uint32_t> objs, float e0, float e1);
   int32_t build_bvh_sah(std::vector<uint32_t> objs, float e0, float e1);
-  void emit(uint32_t obj, bool under_bvh, bool under_and_in_bvh, int depth, FlatScene* out) const;
-  void emit_bvh(int32_t node, int depth, FlatScene* out) const;
+  void emit(uint32_t obj, bool under_bvh, bool under_and_in_bvh, int depth, FlatScene* out, bool in_boundary = false) const;
+  void emit_bvh(int32_t node, int depth, FlatScene* out, bool in_boundary) const;
 };
 
 struct BuildError {

@@ -2,11 +2,13 @@
 on the HIP product.  Every reference constructor can appear: Sphere, Rect, FlipNormals, Translate, Scale,
 RotateY, And, rect_prism, LinearMove, ConstantMedium, nested Bvh, list or Bvh world; all five materials;
 constant / checker / Perlin textures.  Shapes the flattener documents as unsupported are avoided
-(medium boundary = one primitive, at most 4 nested non-fused wrappers, no medium below And below Bvh)."""
+(at most 4 nested non-fused wrappers, no medium below And below Bvh, no medium inside a medium's boundary).
+`general_boundaries=True` additionally draws ConstantMedium boundaries that are object graphs (prisms, And,
+Bvh, transform wrappers) instead of one primitive."""
 import numpy as np
 
 
-def random_world(pkg, b, rs, n_top=6):
+def random_world(pkg, b, rs, n_top=6, general_boundaries=False):
     S = pkg.scenes
     b.set_perlin_tables(*pkg.small_rng.perlin_tables(int(rs.randint(1, 1 << 30))))
 
@@ -42,6 +44,24 @@ def random_world(pkg, b, rs, n_top=6):
         a0, b0 = f(-120, 0), f(-120, 0)
         return b.rect(int(rs.randint(0, 3)), (a0, a0 + f(40, 220)), (b0, b0 + f(40, 220)), f(-60, 60), material())
 
+    def graph_boundary():
+        """object.rs:441 `ConstantMedium<O: Object>`: any object can bound a medium (main.rs only uses spheres)."""
+        def solid():
+            if rs.rand() < 0.5:
+                p0 = vec(-80, 0)
+                return b.rect_prism(p0, p0 + S.v(f(60, 200), f(60, 200), f(60, 200)), material())
+            return b.translate(vec(-60, 60), b.sphere(f(40, 120), material()))
+        k = rs.randint(0, 5)
+        if k == 0:
+            return solid()
+        if k == 1:
+            return b.and_(solid(), solid())
+        if k == 2:
+            return b.bvh([solid() for _ in range(rs.randint(1, 5))], (0.0, 1.0))
+        if k == 3:
+            return b.rotate_y(f(-170, 170), solid())
+        return b.linear_move(b.scale(S.v(f(0.5, 2), f(0.5, 2), f(0.5, 2)), solid()), vec(-40, 40))
+
     def obj(depth, wrappers, under_bvh, in_and_under_bvh):
         k = rs.randint(0, 10)
         if depth >= 3 or k <= 1:
@@ -61,7 +81,7 @@ def random_world(pkg, b, rs, n_top=6):
             o = (b.scale(S.v(f(0.5, 2), f(0.5, 2), f(0.5, 2)), inner) if w == 0 else
                  b.linear_move(inner, vec(-40, 40)) if w == 1 else b.flip_normals(inner))
         elif k == 7 and not in_and_under_bvh:
-            boundary = b.sphere(f(40, 160), material())
+            boundary = graph_boundary() if general_boundaries else b.sphere(f(40, 160), material())
             if rs.rand() < 0.5:
                 boundary = b.translate(vec(-100, 100), boundary)
             if rs.rand() < 0.3:

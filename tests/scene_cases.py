@@ -42,6 +42,20 @@ def _big_lean(pkg, b, nx, ny):
     return [b.bvh(objs, (0.0, 1.0))], cam, (0.0, 1.0)
 
 
+def _cornell_smoke(pkg, b, nx, ny):
+    """The Cornell box with its two prisms turned into smoke: ConstantMedium<O> (object.rs:441) over
+    Translate<RotateY<And<...rects>>> boundaries -- the general (object-graph) boundary walk."""
+    S = pkg.scenes
+    world = S.cornell_box(b)
+    white = b.lambertian(b.constant(S.vfrom(0.73)))
+    box1 = b.translate(S.v(130.0, 0.0, 65.0), b.rotate_y(-18.0, b.rect_prism(S.v(0, 0, 0), S.v(165.0, 165.0, 165.0), white)))
+    box2 = b.translate(S.v(265.0, 0.0, 295.0), b.rotate_y(15.0, b.rect_prism(S.v(0, 0, 0), S.v(165.0, 330.0, 165.0), white)))
+    world.append(b.constant_medium(box1, 0.01, b.isotropic(b.constant(S.vfrom(1.0)))))
+    world.append(b.constant_medium(box2, 0.01, b.isotropic(b.constant(S.vfrom(0.0)))))
+    cam, exp = S._cornell_camera(b.be, nx, ny)
+    return world, cam, exp
+
+
 CASES = {
     # name: (builder fn (pkg, b, nx, ny) -> (world, cam, exposure), nx, ny, ns)
     "cornell": (lambda pkg, b, nx, ny: pkg.scenes.cornell_box_scene(b, nx, ny), 32, 32, 16),
@@ -58,6 +72,7 @@ CASES = {
         b, nx, ny, pkg.small_rng.SmallRng(0xDEADBEEF), spheres=200), 24, 24, 4),
     "checker_scale": (_checker_scale, 32, 32, 8),
     "big_lean": (_big_lean, 40, 24, 6),
+    "cornell_smoke": (_cornell_smoke, 32, 32, 8),
     "book1_sah": (lambda pkg, b, nx, ny: pkg.scenes.random_scene(b, nx, ny, use_bvh="sah"), 48, 32, 8),
 }
 

@@ -118,10 +118,13 @@ def test_reference_error_behaviour(pkg):
     with pytest.raises(pkg.RtError):
         b.rect(5, (0, 1), (0, 1), 0.0, m)
     # shapes the flat program cannot express are refused, never silently approximated
+    iso = b.isotropic(b.constant(S.vfrom(1.0)))
     box = b.rect_prism(S.v(0, 0, 0), S.v(1, 1, 1), m)
-    fog = b.constant_medium(box, 0.1, b.isotropic(b.constant(S.vfrom(1.0))))
-    with pytest.raises(pkg.RtError) as e:
-        b.flatten([fog])
+    words, feat = b.flatten([b.constant_medium(box, 0.1, iso)])   # a boundary may be any object graph ...
+    assert (feat & 16) and words[0, 4] == len(words) - 1
+    nested = b.constant_medium(b.and_(box, b.constant_medium(b.sphere(1.0, m), 0.1, iso)), 0.1, iso)
+    with pytest.raises(pkg.RtError) as e:                         # ... except one that itself holds a medium
+        b.flatten([nested])
     assert e.value.code == -5
     deep = b.sphere(1.0, m)
     for _ in range(6):

@@ -6,12 +6,13 @@ from conftest import assert_bit_equal
 from fuzz_scenes import random_camera, random_world
 
 N_SCENES = 48
+N_BOUNDARY_SCENES = 16
 
 
-def _build(pkg, backend, seed, nx, ny):
+def _build(pkg, backend, seed, nx, ny, general_boundaries=False):
     rs = np.random.RandomState(seed)
     b = backend.builder()
-    world = random_world(pkg, b, rs)
+    world = random_world(pkg, b, rs, general_boundaries=general_boundaries)
     cam = random_camera(pkg, backend, rs, nx, ny)
     return b, world, cam
 
@@ -28,6 +29,25 @@ def test_fuzz_graphs_flatten_on_host(pkg, seed):
     assert int((ops == 4).sum()) == int((ops == 5).sum())          # PUSH / POP balanced
     med = np.nonzero(ops == 6)[0]
     assert np.isin(ops[med + 1], (2, 3)).all()                     # a medium's boundary record follows it
+    assert (words[med, 4] == med + 2).all()                        # ... and the medium names where it ends
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_graph_boundaries_flatten_on_host(pkg, seed):
+    """CPU-only: media bounded by object graphs flatten to MEDIUM + a closed boundary stream."""
+    b, world, _ = _build(pkg, pkg.load(), 5000 + seed, 24, 16, general_boundaries=True)
+    words, feat = b.flatten(world)
+    ops, flags = words[:, 7] & 0xff, words[:, 7]
+    med = np.nonzero(ops == 6)[0]
+    for m in med:
+        end = int(words[m, 4])
+        assert m + 1 < end <= len(words) - 1
+        inner = ops[m + 1:end]
+        assert not np.isin(inner, (0, 6)).any()                    # no END / nested medium inside a boundary
+        assert int((inner == 4).sum()) == int((inner == 5).sum())  # its PUSH / POP pairs close inside it
+        general = bool(flags[m] & (1 << 14))
+        assert general == (end != m + 2) or general
+        assert (not general) or (feat & 16)
 
 
 @pytest.mark.gpu
@@ -41,5 +61,20 @@ def test_fuzz_graphs_bit_exact(pkg, gpu, oracle, seed):
     img_o, st_o = so.par_cast(cam_o, nx, ny, ns, stats=True)
     img_g, st_g = sg.par_cast(cam_g, nx, ny, ns, stats=True)
     assert_bit_equal(img_g, img_o, "fuzz scene %d" % seed)
+    for k in ("aabb_tests", "prim_tests", "shaded_hits", "rays", "draws"):
+        assert st_g[k] == st_o[k], (seed, k, st_g[k], st_o[k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(N_BOUNDARY_SCENES))
+def test_fuzz_graph_boundaries_bit_exact(pkg, gpu, oracle, seed):
+    """ConstantMedium<O> with O an object graph (object.rs:441-497): nested boundary walk vs the oracle."""
+    nx, ny, ns = 40, 24, 5
+    bg, wg, cam_g = _build(pkg, gpu, 5000 + seed, nx, ny, True)
+    bo, wo, cam_o = _build(pkg, oracle, 5000 + seed, nx, ny, True)
+    sg, so = bg.scene(wg), bo.scene(wo)
+    img_o, st_o = so.par_cast(cam_o, nx, ny, ns, stats=True)
+    img_g, st_g = sg.par_cast(cam_g, nx, ny, ns, stats=True)
+    assert_bit_equal(img_g, img_o, "boundary fuzz scene %d" % seed)
     for k in ("aabb_tests", "prim_tests", "shaded_hits", "rays", "draws"):
         assert st_g[k] == st_o[k], (seed, k, st_g[k], st_o[k])
