@@ -79,21 +79,41 @@ struct PoolTuning {
   uint32_t box_leave;    // lanes leaving the BOX state before a box run re-evaluates the schedule
 };
 
-// dynamic LDS bytes for a workgroup of `waves` waves.  The path slots live either in LDS (80 B x 128 per
-// wave: caps a CU at 8 waves) or in a per-wave SoA region of global memory (L2-resident; a field access
-// of 64 lanes touches at most 4 cache lines), which leaves LDS to the program and lets 16 waves share a CU.
-inline size_t pool_lds_bytes(uint32_t n_prog, uint32_t n_mat, uint32_t waves, bool stage_program, bool slots_in_lds) {
-  size_t b = stage_program ? ((size_t)n_prog * 32 + (size_t)n_mat * 32) : 0;
-  if (slots_in_lds) b += (size_t)waves * POOL * POOL_FIELDS * 4;  // slots
-  b += (size_t)waves * POOL * 3 * 2;                              // T-, S- and E-list (u16 slot ids)
+// LDS image of the program (staged variant): one 48-byte record per instruction, pc = 48 r.
+//   BOX     dw0-2 (max.x, min.x, max.x)  dw3-5 (max.y, min.y, max.y)  dw6-8 (max.z, min.z, max.z)
+//           dw10 skip pc   dw11 op/flags | LDS_BOX_BIT
+//   others  dw0-3 = lo, dw4-7 = hi, dw11 = op/flags
+// pc is the record's absolute LDS address (a step forms no base + offset sum); "is this a BOX" is the
+// sign bit of the flag word (one compare, no mask).
+// Aabb::hit swaps (t0, t1) when 1/d < 0 (aabb.rs:20-23).  With the plane triple (max, min, max) a lane
+// reads ITS (near plane, far plane) pair with one 8-byte load at byte 4 (1/d >= 0: (min, max)) or byte 0
+// (1/d < 0: (max, min)); the offset is fixed per ray, so the swap costs no instruction per step.
+constexpr uint32_t LDS_REC = 48;
+constexpr uint32_t LDS_BOX_BIT = 0x80000000u;
+typedef __attribute__((address_space(3))) const char* lds_cptr;
+
+// dynamic LDS bytes for a workgroup of `waves` waves.  The path slots live in a per-wave SoA region of
+// global memory (L2-resident; a field access of 64 lanes touches at most 4 cache lines), which leaves
+// LDS to the program and lets 16 waves share a CU.
+inline size_t pool_lds_bytes(uint32_t n_prog, uint32_t n_mat, uint32_t waves, bool stage_program) {
+  size_t b = stage_program ? ((size_t)n_prog * LDS_REC + (size_t)n_mat * 32) : 0;
+  b += (size_t)waves * POOL * 3 * 2;  // T-, S- and E-list (u16 slot ids)
   return (b + 15) & ~(size_t)15;
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef f32x2 f32x2_a4 __attribute__((aligned(4)));   // 4-byte aligned pair: lowers to ds_read2_b32
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define RT_AS3(type_, addr_) (*(const __attribute__((address_space(3))) type_*)(uintptr_t)(addr_))
+RT_DEV uint4 lds_u4(uint32_t a) {  // ds_read_b128 at an absolute LDS address
+  const u32x4 v = RT_AS3(u32x4, a);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
 
 RT_DEV bool hi_is_root(uint4 hi) { return (hi.w & F_BVH_ROOT) != 0u; }
 
-RT_DEV uint4 fetch_hi_global(const DevScene& sc, uint32_t idx) {  // byte-offset skip pointers, global-memory variant
+RT_DEV uint4 fetch_hi_global(const DevScene& sc, uint32_t idx) {  // byte-offset (16 r) skip pointers, global-memory variants
   uint4 h = sc.hi[idx];
   if ((h.w & 0xffu) == OP_BOX) h.z *= 16u;
   if ((h.w & 0xffu) == OP_MEDIUM) h.x *= 16u;  // end of the boundary's stream
@@ -101,7 +121,7 @@ RT_DEV uint4 fetch_hi_global(const DevScene& sc, uint32_t idx) {  // byte-offset
 }
 
 #ifndef RT_POOL_MAX_THREADS
-#define RT_POOL_MAX_THREADS 512
+#define RT_POOL_MAX_THREADS 1024
 #endif
 #ifndef RT_POOL_WAVES_PER_EU
 #define RT_POOL_WAVES_PER_EU 1
@@ -118,37 +138,38 @@ RT_DEV uint4 fetch_hi_global(const DevScene& sc, uint32_t idx) {  // byte-offset
 // Each pass type runs 64 lanes wide over slots of ITS class, so a wave no longer issues the union of
 // the scatter code and the camera code for every batch of finished rays.  The class of a hit is read
 // from the winning SPHERE record (the flattener copies the material kind into its flag word).
-template <bool USE_LDS, bool SLOTS_LDS, bool COUNT>
+template <bool USE_LDS, bool COUNT>
 __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void render_lean_pool(
     DevScene sc, DevCamera cam, DevParams P, float* __restrict__ out, uint32_t total_work, uint32_t* __restrict__ queue,
     unsigned long long* counters, PoolTuning tune, ChunkMode cm, uint32_t* __restrict__ g_slots) {
   extern __shared__ uint4 s_mem[];
   const uint32_t n_prog = sc.n_prog;
-  const uint32_t staged = USE_LDS ? 2u * n_prog + 2u * sc.n_mat : 0u;  // uint4 units
-  // Program counters are BYTE offsets (16 r) into the staged lo[] array; hi[] follows at +16 n.  A step
-  // needs no shift (ds_read_b128 pc ; ds_read_b128 pc + hi_off) and BOX skip pointers are stored
-  // pre-multiplied.  SoA (not 32-byte AoS records): a b128 gather of 16-byte packets then spreads over
-  // all 64 LDS banks.
-  const uint32_t hi_off = 16u * n_prog;
+  // Program counters are BYTE offsets: REC r.  Staged: into the LDS image above (a step needs no shift,
+  // BOX skip pointers are stored pre-multiplied).  Not staged (program larger than LDS): REC = 16 and
+  // (lo, hi) come from global memory.
+  constexpr uint32_t REC = USE_LDS ? LDS_REC : 16u;
+  const uint32_t staged = USE_LDS ? 3u * n_prog + 2u * sc.n_mat : 0u;  // uint4 units
+  const uint32_t pc0 = USE_LDS ? (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)s_mem : 0u;  // pc of record 0
   if (USE_LDS) {
     for (uint32_t i = threadIdx.x; i < n_prog; i += blockDim.x) {
-      uint4 h = sc.hi[i];
-      if ((h.w & 0xffu) == OP_BOX) h.z *= 16u;
-      s_mem[i] = sc.lo[i];
-      s_mem[n_prog + i] = h;
+      const uint4 l = sc.lo[i], h = sc.hi[i];
+      uint4 a = l, b = h, c = make_uint4(0u, 0u, 0u, h.w);
+      if ((h.w & 0xffu) == OP_BOX) {  // lo = (min.x, max.x, min.y, max.y), hi = (min.z, max.z, skip, flags)
+        a = make_uint4(l.y, l.x, l.y, l.w);
+        b = make_uint4(l.z, l.w, h.y, h.x);
+        c = make_uint4(h.y, 0u, pc0 + h.z * LDS_REC, h.w | LDS_BOX_BIT);
+      }
+      s_mem[3u * i] = a, s_mem[3u * i + 1u] = b, s_mem[3u * i + 2u] = c;
     }
-    for (uint32_t i = threadIdx.x; i < 2u * sc.n_mat; i += blockDim.x) s_mem[2u * n_prog + i] = sc.mat[i];
+    for (uint32_t i = threadIdx.x; i < 2u * sc.n_mat; i += blockDim.x) s_mem[3u * n_prog + i] = sc.mat[i];
   }
-  const char* s_bytes = reinterpret_cast<const char*>(s_mem);
-#define RT_FETCH_LO(pc_) (USE_LDS ? *reinterpret_cast<const uint4*>(s_bytes + (pc_)) : sc.lo[(pc_) >> 4])
-#define RT_FETCH_HI(pc_) (USE_LDS ? *reinterpret_cast<const uint4*>(s_bytes + hi_off + (pc_)) : fetch_hi_global(sc, (pc_) >> 4))
-#define RT_FETCH_MAT(i_) (USE_LDS ? s_mem[2u * n_prog + (i_)] : sc.mat[(i_)])
+#define RT_FETCH_LO(pc_) (USE_LDS ? lds_u4(pc_) : sc.lo[(pc_) >> 4])
+#define RT_FETCH_HI(pc_) (USE_LDS ? lds_u4((pc_) + 16u) : fetch_hi_global(sc, (pc_) >> 4))
+#define RT_FETCH_MAT(i_) (USE_LDS ? s_mem[3u * n_prog + (i_)] : sc.mat[(i_)])
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, n_waves = blockDim.x >> 6;
-  uint32_t* pool_base = reinterpret_cast<uint32_t*>(s_mem + staged);
-  uint32_t* slot = SLOTS_LDS ? pool_base + wave * (POOL * POOL_FIELDS)
-                             : g_slots + ((size_t)blockIdx.x * n_waves + wave) * (POOL * POOL_FIELDS);
+  uint32_t* slot = g_slots + ((size_t)blockIdx.x * n_waves + wave) * (POOL * POOL_FIELDS);
   float* slotf = reinterpret_cast<float*>(slot);
-  uint16_t* tlist = reinterpret_cast<uint16_t*>(pool_base + (SLOTS_LDS ? n_waves * (POOL * POOL_FIELDS) : 0u)) + wave * (3u * POOL);
+  uint16_t* tlist = reinterpret_cast<uint16_t*>(s_mem + staged) + wave * (3u * POOL);
   uint16_t* slist = tlist + POOL;
   uint16_t* elist = slist + POOL;
 #define SLOT_U(f_, j_) slot[(f_)*POOL + (j_)]
@@ -172,30 +193,47 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
   V3 o = mk(0.f, 0.f, 0.f), d = o, inv = o;
   uint32_t pc = 0, best_pc = NO_HIT, best_flags = 0;
   float best = F32_MAX;
-  uint4 cur_lo = make_uint4(0, 0, 0, 0), cur_hi = make_uint4(0, 0, 0, OP_END);
+  // the record at pc as the box step wants it: per axis (near plane, far plane), skip pc, op/flags
+  f32x2 cx = {0.f, 0.f}, cy = cx, cz = cx;
+  uint32_t c_skip = 0, c_flags = 0xffu;
+  uint32_t sgn_x = 0, sgn_y = 0, sgn_z = 0;  // staged: byte offset of this ray's plane pair inside each triple
   Counts cnt = {0, 0, 0, 0};
   uint32_t total_draws = 0;
   uint32_t n_box_it = 0, n_box_lanes = 0, n_sph_it = 0, n_sph_lanes = 0, n_shade = 0, n_shade_lanes = 0, n_refill = 0;
   uint32_t n_end = 0, n_end_lanes = 0;
   unsigned long long t_shade = 0, t_serv = 0, t_box = 0, t_sph = 0, t_mark = 0, t_mark2 = 0;  // COUNT: s_memtime shares
 
+  // load the record at pc into (cx, cy, cz, c_skip, c_flags)
+#define RT_LOAD_REC() \
+        if (USE_LDS) { \
+          cx = RT_AS3(f32x2_a4, pc + sgn_x); \
+          cy = RT_AS3(f32x2_a4, pc + sgn_y); \
+          cz = RT_AS3(f32x2_a4, pc + sgn_z); \
+          const u32x2 sf_ = RT_AS3(u32x2, pc + 40u); \
+          c_skip = sf_.x, c_flags = sf_.y; \
+        } else { \
+          const uint4 l_ = sc.lo[pc >> 4], h_ = sc.hi[pc >> 4]; \
+          cx = inv.x < 0.f ? f32x2{u2f(l_.y), u2f(l_.x)} : f32x2{u2f(l_.x), u2f(l_.y)}; \
+          cy = inv.y < 0.f ? f32x2{u2f(l_.w), u2f(l_.z)} : f32x2{u2f(l_.z), u2f(l_.w)}; \
+          cz = inv.z < 0.f ? f32x2{u2f(h_.y), u2f(h_.x)} : f32x2{u2f(h_.x), u2f(h_.y)}; \
+          c_skip = h_.z * 16u, c_flags = h_.w; \
+        }
+  // Aabb::hit, aabb.rs:16-27, packed: per axis (t_near_plane, t_far_plane) = ((planes) - o) * inv -- the
+  // same two products as the reference's (t0, t1), already in swapped order
+#define RT_IS_BOX() (USE_LDS ? (int32_t)c_flags < 0 : (c_flags & 0xffu) == OP_BOX)
 #define RT_BOX_STEP() \
-        if (op == OP_BOX) { \
+        if (RT_IS_BOX()) { \
           if (COUNT) cnt.aabb++; \
-          const f32x2 tx = (f32x2{u2f(cur_lo.x), u2f(cur_lo.y)} - f32x2{o.x, o.x}) * f32x2{inv.x, inv.x}; \
-          const f32x2 ty = (f32x2{u2f(cur_lo.z), u2f(cur_lo.w)} - f32x2{o.y, o.y}) * f32x2{inv.y, inv.y}; \
-          const f32x2 tz = (f32x2{u2f(cur_hi.x), u2f(cur_hi.y)} - f32x2{o.z, o.z}) * f32x2{inv.z, inv.z}; \
-          float ax = neg_x ? tx.y : tx.x, bx = neg_x ? tx.x : tx.y; \
-          float ay = neg_y ? ty.y : ty.x, by = neg_y ? ty.x : ty.y; \
-          float az = neg_z ? tz.y : tz.x, bz = neg_z ? tz.x : tz.y; \
-          float start = rs_max(t_near, rs_max(rs_max(ax, ay), az)); \
-          float end = rs_min(best, rs_min(rs_min(bx, by), bz)); \
-          pc = (end > start) ? pc + 16u : cur_hi.z; \
-          cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc); \
-          op = cur_hi.w & 0xffu; \
+          const f32x2 tx = (cx - f32x2{o.x, o.x}) * f32x2{inv.x, inv.x}; \
+          const f32x2 ty = (cy - f32x2{o.y, o.y}) * f32x2{inv.y, inv.y}; \
+          const f32x2 tz = (cz - f32x2{o.z, o.z}) * f32x2{inv.z, inv.z}; \
+          float start = rs_max(t_near, rs_max(rs_max(tx.x, ty.x), tz.x)); \
+          float end = rs_min(best, rs_min(rs_min(tx.y, ty.y), tz.y)); \
+          pc = (end > start) ? pc + REC : c_skip; \
+          RT_LOAD_REC(); \
         }
   for (;;) {
-    uint32_t op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
+    uint32_t op = have_ray ? (c_flags & 0xffu) : 0xffu;
     const uint64_t m_box = __builtin_amdgcn_ballot_w64(op == OP_BOX);
     const uint64_t m_sph = __builtin_amdgcn_ballot_w64(op == OP_SPHERE);
     const uint32_t n_busy = (uint32_t)__builtin_popcountll(m_box | m_sph);
@@ -214,6 +252,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           if (to_e) elist[e_count + lane_rank(m_e)] = (uint16_t)my_slot;
           else slist[s_count + lane_rank(m_s)] = (uint16_t)my_slot;
           have_ray = false;
+          c_flags = 0xffu;  // no record: the box loop tests c_flags alone
         }
         e_count += (uint32_t)__builtin_popcountll(m_e);
         s_count += (uint32_t)__builtin_popcountll(m_s);
@@ -447,8 +486,9 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
             o = mk(SLOT_F(PF_O, my_slot), SLOT_F(PF_O + 1, my_slot), SLOT_F(PF_O + 2, my_slot));
             d = mk(SLOT_F(PF_D, my_slot), SLOT_F(PF_D + 1, my_slot), SLOT_F(PF_D + 2, my_slot));
             inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);  // aabb.rs:17
-            pc = 0, best = F32_MAX, best_pc = NO_HIT, best_flags = 0;
-            cur_lo = RT_FETCH_LO(0), cur_hi = RT_FETCH_HI(0);
+            sgn_x = inv.x < 0.f ? 0u : 4u, sgn_y = inv.y < 0.f ? 12u : 16u, sgn_z = inv.z < 0.f ? 24u : 28u;  // aabb.rs:20-23
+            pc = pc0, best = F32_MAX, best_pc = NO_HIT, best_flags = 0;
+            RT_LOAD_REC();
             have_ray = true;
           }
           t_count -= got;
@@ -458,7 +498,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
       if (COUNT) t_serv += RT_TICK() - t_mark;
       if (n_dead == POOL) break;  // every slot retired: this wave is done
       if (__builtin_amdgcn_ballot_w64(have_ray) == 0) continue;  // nothing to traverse yet: service again
-      op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
+      op = have_ray ? (c_flags & 0xffu) : 0xffu;
     }
     // ============================== TRAVERSE ======================================================
     const uint64_t b_box = __builtin_amdgcn_ballot_w64(op == OP_BOX);
@@ -469,14 +509,13 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
       const uint32_t n0 = (uint32_t)__builtin_popcountll(b_box);
       const uint32_t floor_lanes = n0 > tune.box_leave ? n0 - tune.box_leave : 0u;
       uint32_t n_now;
-      const bool neg_x = inv.x < 0.f, neg_y = inv.y < 0.f, neg_z = inv.z < 0.f;  // aabb.rs:20-23
       do {
         if (COUNT) n_box_it++;
-        RT_BOX_STEP();  // Aabb::hit, aabb.rs:16-27, packed: per axis (t0, t1) = ((min, max) - o) * inv
+        RT_BOX_STEP();
 #if RT_BOX_UNROLL >= 2
         RT_BOX_STEP();  // lanes that left the BOX state sit this one out; the schedule check runs every other step
 #endif
-        n_now = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op == OP_BOX));
+        n_now = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(RT_IS_BOX()));
         if (COUNT) n_box_lanes += n_now;
       } while (n_now > floor_lanes);
       if (COUNT) t_box += RT_TICK() - t_mark;
@@ -484,16 +523,17 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
       if (COUNT) n_sph_it++, n_sph_lanes += (uint32_t)__builtin_popcountll(b_sph), t_mark = RT_TICK();
       if (op == OP_SPHERE) {  // Sphere::hit, object.rs:84-111 (+ Translate :275)
         if (COUNT) cnt.prim++;
+        const uint4 slo = RT_FETCH_LO(pc);  // (offset.xyz, radius)
         V3 lo_o = o;
-        if (cur_hi.w & F_TRANSLATE) lo_o = vsub(o, mk(u2f(cur_lo.x), u2f(cur_lo.y), u2f(cur_lo.z)));
+        if (c_flags & F_TRANSLATE) lo_o = vsub(o, mk(u2f(slo.x), u2f(slo.y), u2f(slo.z)));
         float t;
-        if (sphere_hit_t(lo_o, d, u2f(cur_lo.w), t_near, best, t)) {
+        if (sphere_hit_t(lo_o, d, u2f(slo.w), t_near, best, t)) {
           best = t;
           best_pc = pc;
-          best_flags = cur_hi.w;
+          best_flags = c_flags;
         }
-        pc += 16u;
-        cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc);
+        pc += REC;
+        RT_LOAD_REC();
       }
       if (COUNT) t_sph += RT_TICK() - t_mark;
     }
@@ -516,6 +556,8 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
     }
   }
 #undef RT_BOX_STEP
+#undef RT_LOAD_REC
+#undef RT_IS_BOX
 #undef RT_FETCH_LO
 #undef RT_FETCH_HI
 #undef RT_FETCH_MAT

@@ -160,7 +160,6 @@ struct rtg_scene {
   size_t stack_bytes = 0;
   uint32_t* d_slots = nullptr;  // ray-pool path slots when they live in global memory
   size_t slots_bytes = 0;
-  int slots_in_lds = 0;         // RTG_SLOTS_LDS=1: keep the path slots in LDS (8 waves/CU)
   float* d_scratch = nullptr;  // chunk-mode per-sample colours
   size_t scratch_bytes = 0;
   int force_chunks = 0;        // RTG_CHUNKS: 0 = automatic
@@ -170,6 +169,7 @@ struct rtg_scene {
   PoolTuning pool_tune{20, 16, 32};
   Tuning tune{24, 16, 8};
   int block_threads = 512, wg_per_cu = 0;  // 0 = ask the occupancy API
+  int pool_threads = 1024;                 // lean ray-pool kernel: ONE 16-wave workgroup per CU shares one LDS copy of the program
 };
 
 // The per-sample colour scratch may take up to half of the free HBM (288 GB per MI355X).
@@ -212,7 +212,7 @@ static hipError_t launch_persistent(const rtg_scene* s, const DevCamera& cam, co
   return hipGetLastError();
 }
 
-// Lean scenes, ray-pool kernel (rt_pool.h): one persistent 512-thread workgroup per CU.
+// Lean scenes, ray-pool kernel (rt_pool.h): one persistent 1024-thread workgroup per CU.
 template <bool COUNT>
 static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParams& d, float* d_out,
                               hipStream_t stream) {
@@ -221,7 +221,7 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
   uint32_t owned = tiles > d.rank ? (tiles - d.rank + d.nranks - 1) / d.nranks : 0;
   const uint64_t pix_work = (uint64_t)owned * d.tile_w * d.tile_h;
   if (pix_work == 0) return hipSuccess;  // this rank owns no tile
-  const int bt = s->block_threads;
+  const int bt = s->pool_threads;
   const uint32_t waves = (uint32_t)bt / 64;
   // sample-chunk mode (see rt_pool.h)
   ChunkMode cm{nullptr, d.ns, 1, (uint32_t)pix_work};
@@ -252,13 +252,11 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
   hipError_t e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream);  // re-initialise every call
   if (e != hipSuccess) return e;
   const size_t lds_limit = 160 * 1024;
-  const bool slots_lds = s->slots_in_lds != 0;
-  bool use_lds = pool_lds_bytes(s->n_prog, s->n_mat, waves, true, slots_lds) <= lds_limit;
-  size_t lds = pool_lds_bytes(s->n_prog, s->n_mat, waves, use_lds, slots_lds);
+  bool use_lds = pool_lds_bytes(s->n_prog, s->n_mat, waves, true) <= lds_limit;
+  size_t lds = pool_lds_bytes(s->n_prog, s->n_mat, waves, use_lds);
   void (*kernel)(DevScene, DevCamera, DevParams, float*, uint32_t, uint32_t*, unsigned long long*, PoolTuning, ChunkMode,
                  uint32_t*);
-  if (slots_lds) kernel = use_lds ? render_lean_pool<true, true, COUNT> : render_lean_pool<false, true, COUNT>;
-  else kernel = use_lds ? render_lean_pool<true, false, COUNT> : render_lean_pool<false, false, COUNT>;
+  kernel = use_lds ? render_lean_pool<true, COUNT> : render_lean_pool<false, COUNT>;
   e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   int per_cu = s->wg_per_cu;
@@ -273,7 +271,7 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
   if (getenv("RTG_VERBOSE"))
     fprintf(stderr, "[rtg] pool: grid %u x %d threads, %d WG/CU, lds %zu B (program staged: %d), %u chunk(s) of %u samples\n", grid,
             bt, per_cu, lds, (int)use_lds, cm.n_chunks, cm.chunk);
-  if (!slots_lds) {
+  {
     size_t need = (size_t)grid * waves * POOL * POOL_FIELDS * sizeof(uint32_t);
     if (need > s->slots_bytes) {
       if (s->d_slots) (void)hipFree(s->d_slots);
@@ -704,8 +702,7 @@ int rtg_scene_create(rtg_builder* b, const rtg_id* world, size_t n, int device, 
   if (s->num_cus <= 0) s->num_cus = 256;
   if (const char* kv = getenv("RTG_KERNEL")) s->kernel_version = atoi(kv);  // A/B switches for measurements
   if (const char* kv = getenv("RTG_CHUNKS")) s->force_chunks = atoi(kv);
-  if (const char* kv = getenv("RTG_SLOTS_LDS")) s->slots_in_lds = atoi(kv);
-  if (const char* kv = getenv("RTG_BLOCK")) s->block_threads = atoi(kv);
+  if (const char* kv = getenv("RTG_BLOCK")) s->block_threads = s->pool_threads = atoi(kv);
   if (const char* kv = getenv("RTG_WG_PER_CU")) s->wg_per_cu = atoi(kv);
   if (const char* kv = getenv("RTG_REGEN_MIN")) s->tune.regen_min = (uint32_t)atoi(kv);
   if (const char* kv = getenv("RTG_SPHERE_MIN")) s->tune.sphere_min = (uint32_t)atoi(kv);
