@@ -25,7 +25,10 @@
 
 namespace rtg {
 
-constexpr uint32_t POOL = 192;           // path slots per wave: 64 in lanes + 128 waiting, so one wait list always holds >= 64
+#ifndef RT_POOL_SLOTS
+#define RT_POOL_SLOTS 192  // 160-192 measured best on C2; 256+ costs 20-40 % (slot working set vs L2, longer tail)
+#endif
+constexpr uint32_t POOL = RT_POOL_SLOTS;           // path slots per wave: 64 in lanes + 128 waiting, so one wait list always holds >= 64
 constexpr uint32_t POOL_FIELDS = 20;     // dwords per slot (SoA: field f of slot j at [f * POOL + j])
 constexpr uint32_t WORK_BLOCK = 256;     // work items a wave reserves per global atomic (2048 cost 20 % on C2: ~6 blocks per wave = a coarse tail)
 constexpr uint32_t SLOT_NEED_PIXEL = 0xfffffffeu;  // best_pc marker: slot holds no ray yet
