@@ -14,6 +14,8 @@
 //   Translate/Scale/RotateY/LinearMove/FlipNormals over a subtree -> PUSH, subtree, POP
 //   Sphere, Translate{Sphere}, FlipNormals thereof -> one fused SPHERE record
 //   Rect<A>, FlipNormals(Rect<A>)                  -> one RECT record
+//   rect_prism(p0, p1, m) (the exact And-tree of object.rs:420-473) -> one PRISM record
+//   Translate{RotateY{x}}, Translate{LinearMove{x}} -> ONE PUSH/POP pair (F_PRE_TRANSLATE): same arithmetic, in sequence
 //   ConstantMedium{boundary}                       -> MEDIUM{end} followed by the boundary's own stream (one fused
 //                                                     primitive record in every reference scene; any object graph without
 //                                                     a nested medium otherwise), skipped by the main walk
@@ -34,6 +36,8 @@ enum Op : uint32_t {
   OP_PUSH = 4,    // lo = (a, b, c, -)                   hi = (-, -, matching_pop, op|kind)
   OP_POP = 5,     // lo = (a, b, c, -)                   hi = (-, -, matching_push, op|kind)
   OP_MEDIUM = 6,  // lo = (density, -, -, -)             hi = (end_pc, -, material, op|flags); boundary = records (pc, end_pc)
+  OP_PRISM = 7,   // lo = (p0.x, p1.x, p0.y, p1.y)       hi = (p0.z, p1.z, material, op|flags): rect_prism(p0, p1, material)
+                  //      (object.rs:420-473), its six Rect::hit in the And-tree's order inside ONE instruction
 };
 
 // flag bits in hi.w above the 8-bit opcode
@@ -45,6 +49,8 @@ constexpr uint32_t F_BVH_ROOT = 1u << 13;   // BOX: root of an outermost Bvh (a 
 constexpr uint32_t F_GENERAL_BOUNDARY = 1u << 14;  // MEDIUM: the boundary is an object graph (several records), not one primitive
 constexpr uint32_t F_MATKIND_SHIFT = 16;    // SPHERE/RECT/MEDIUM: bits 16-18 = MatKind of the record's material (copy, for schedulers)
 constexpr uint32_t F_KIND_SHIFT = 8;        // PUSH/POP: bits 8-10 = XformKind
+constexpr uint32_t F_PRE_TRANSLATE = 1u << 11;  // PUSH/POP (RotateY / LinearMove): an enclosing Translate rides along,
+                                                // offset = (lo.w, hi.x, hi.y): applied first on the way in, last on the way out
 
 enum XformKind : uint32_t {
   XF_TRANSLATE = 0,  // (a,b,c) = offset               object.rs:267-283

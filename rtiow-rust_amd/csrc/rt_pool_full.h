@@ -111,7 +111,7 @@ __global__ __launch_bounds__(512) void render_full_pool(DevScene sc, DevCamera c
   for (;;) {
     uint32_t op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
     const uint64_t m_box = __builtin_amdgcn_ballot_w64(op == OP_BOX);
-    const uint64_t m_slow = __builtin_amdgcn_ballot_w64(op >= OP_SPHERE && op <= OP_MEDIUM);
+    const uint64_t m_slow = __builtin_amdgcn_ballot_w64(op >= OP_SPHERE && op <= OP_PRISM);
     const uint32_t n_busy = (uint32_t)__builtin_popcountll(m_box | m_slow);
     // ============================== SERVICE ======================================================
     if (64u - n_busy >= tune.refill_min || n_busy == 0) {
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(512) void render_full_pool(DevScene sc, DevCamera c
     }
     // ============================== TRAVERSE ======================================================
     const uint64_t b_box = __builtin_amdgcn_ballot_w64(op == OP_BOX);
-    const uint64_t b_slow = __builtin_amdgcn_ballot_w64(op >= OP_SPHERE && op <= OP_MEDIUM);
+    const uint64_t b_slow = __builtin_amdgcn_ballot_w64(op >= OP_SPHERE && op <= OP_PRISM);
     if (b_box != 0 && (uint32_t)__builtin_popcountll(b_slow) < tune.sphere_min) {
       const uint32_t n0 = (uint32_t)__builtin_popcountll(b_box);
       const uint32_t floor_lanes = n0 > tune.box_leave ? n0 - tune.box_leave : 0u;
@@ -389,12 +389,23 @@ __global__ __launch_bounds__(512) void render_full_pool(DevScene sc, DevCamera c
           best = t, tag = depth, nhits++;
         }
         pc += 16u;
+      } else if (op == OP_PRISM) {  // rect_prism: six Rect::hit in one instruction
+        if (COUNT) cnt.prim += 6;
+        float t;
+        uint32_t face = 0;
+        const uint32_t nh = prism_hit_t(cur_lo, cur_hi, o, d, t_near, best, t, face);
+        if (nh) {
+          hp = vadd(o, smul(t, d)), hn = prism_normal(face), hmat = cur_hi.z;
+          best = t, tag = depth, nhits += nh;
+        }
+        pc += 16u;
       } else if (op == OP_PUSH) {
         const uint32_t kind = (cur_hi.w >> F_KIND_SHIFT) & 7u;
         float* sp = stack + depth * (6u * 64u) + lane;
         sp[0] = o.x, sp[64] = o.y, sp[128] = o.z, sp[192] = d.x, sp[256] = d.y, sp[320] = d.z;
         depth++;
         const V3 a = mk(u2f(cur_lo.x), u2f(cur_lo.y), u2f(cur_lo.z));
+        if (cur_hi.w & F_PRE_TRANSLATE) o = vsub(o, mk(u2f(cur_lo.w), u2f(cur_hi.x), u2f(cur_hi.y)));
         if (kind == XF_TRANSLATE) {
           o = vsub(o, a);
         } else if (kind == XF_ROTATE_Y) {
@@ -421,6 +432,7 @@ __global__ __launch_bounds__(512) void render_full_pool(DevScene sc, DevCamera c
           } else if (kind == XF_FLIP) {
             hn = vneg(hn);
           }
+          if (cur_hi.w & F_PRE_TRANSLATE) hp = vadd(hp, mk(u2f(cur_lo.w), u2f(cur_hi.x), u2f(cur_hi.y)));
           tag = depth;
         }
         const float* sp = stack + depth * (6u * 64u) + lane;
@@ -456,7 +468,7 @@ __global__ __launch_bounds__(512) void render_full_pool(DevScene sc, DevCamera c
         }
         pc = cur_hi.x;  // first record after the boundary's stream
       }
-      if (op >= OP_SPHERE && op <= OP_MEDIUM) cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc);
+      if (op >= OP_SPHERE && op <= OP_PRISM) cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc);
       if (COUNT) t_slow += RT_TICK() - t_mark;
     }
   }

@@ -76,6 +76,29 @@ RT_DEV bool rect_hit_t(V3 o, V3 d, uint32_t axis, float k, float r0s, float r0e,
   return true;
 }
 
+// rect_prism(p0, p1, m), object.rs:420-473: And(And(+Z, And(+Y, +X)), And(Flip(-Z), And(Flip(-Y), Flip(-X)))).
+// `And` tries its second object with the range already shrunk to the first one's hit and a later hit
+// replaces an earlier one (object.rs:403-409), so the six Rect::hit run in that order against a shrinking
+// `best`.  Returns the number of faces that hit (0 = None); `face` = axis | 4 when the normal is flipped.
+RT_DEV uint32_t prism_hit_t(const uint4 lo, const uint4 hi, V3 o, V3 d, float t0, float t1, float& t_out, uint32_t& face) {
+  const float p0x = u2f(lo.x), p1x = u2f(lo.y), p0y = u2f(lo.z), p1y = u2f(lo.w), p0z = u2f(hi.x), p1z = u2f(hi.y);
+  uint32_t n = 0;
+  float best = t1, t;
+  if (rect_hit_t(o, d, 2u, p1z, p0x, p1x, p0y, p1y, t0, best, t)) best = t, face = 2u, n++;
+  if (rect_hit_t(o, d, 1u, p1y, p0x, p1x, p0z, p1z, t0, best, t)) best = t, face = 1u, n++;
+  if (rect_hit_t(o, d, 0u, p1x, p0y, p1y, p0z, p1z, t0, best, t)) best = t, face = 0u, n++;
+  if (rect_hit_t(o, d, 2u, p0z, p0x, p1x, p0y, p1y, t0, best, t)) best = t, face = 2u | 4u, n++;
+  if (rect_hit_t(o, d, 1u, p0y, p0x, p1x, p0z, p1z, t0, best, t)) best = t, face = 1u | 4u, n++;
+  if (rect_hit_t(o, d, 0u, p0x, p0y, p1y, p0z, p1z, t0, best, t)) best = t, face = 0u | 4u, n++;
+  t_out = best;
+  return n;
+}
+RT_DEV V3 prism_normal(uint32_t face) {  // object.rs:212 + FlipNormals (object.rs:249-252)
+  const uint32_t axis = face & 3u;
+  V3 n = mk(axis == 0 ? 1.f : 0.f, axis == 1 ? 1.f : 0.f, axis == 2 ? 1.f : 0.f);
+  return (face & 4u) ? vneg(n) : n;
+}
+
 // object.rs:349-355
 RT_DEV V3 rot_y(V3 p, float s, float c) {
   return mk(vdot(p, mk(c, 0.f, s)), vdot(p, mk(0.f, 1.f, 0.f)), vdot(p, mk(-s, 0.f, c)));
@@ -133,11 +156,18 @@ __device__ __attribute__((noinline)) bool boundary_hit_t(const DevScene& sc, uin
       if (rect_hit_t(o, d, (hi.w >> F_AXIS_SHIFT) & 3u, u2f(lo.x), u2f(lo.y), u2f(lo.z), u2f(lo.w), u2f(hi.x), t_lo, best, t))
         best = t, any = true;
       pc++;
+    } else if (op == OP_PRISM) {
+      if (COUNT) cnt.prim += 6;
+      float t;
+      uint32_t face;
+      if (prism_hit_t(lo, hi, o, d, t_lo, best, t, face)) best = t, any = true;
+      pc++;
     } else if (op == OP_PUSH) {
       const uint32_t kind = (hi.w >> F_KIND_SHIFT) & 7u;
       so[depth] = o, sd[depth] = d;
       depth++;
       const V3 a = mk(u2f(lo.x), u2f(lo.y), u2f(lo.z));
+      if (hi.w & F_PRE_TRANSLATE) o = vsub(o, mk(u2f(lo.w), u2f(hi.x), u2f(hi.y)));
       if (kind == XF_TRANSLATE) {
         o = vsub(o, a);
       } else if (kind == XF_ROTATE_Y) {
@@ -226,11 +256,24 @@ RT_DEV bool hit_top(const DevScene& sc, V3 o, V3 d, float time, float t_near, Sa
       pc++;
       continue;
     }
+    if ((FEAT & FEAT_RECT) && op == OP_PRISM) {
+      if (COUNT) cnt.prim += 6;
+      float t;
+      uint32_t face = 0;
+      const uint32_t nh = prism_hit_t(lo, hi, o, d, t_near, best, t, face);
+      if (nh) {
+        rec.t = t, rec.p = vadd(o, smul(t, d)), rec.n = prism_normal(face), rec.mat = hi.z;
+        best = t, any = true, tag = depth, nhits += nh;
+      }
+      pc++;
+      continue;
+    }
     if ((FEAT & FEAT_XFORM) && op == OP_PUSH) {
       uint32_t kind = (hi.w >> F_KIND_SHIFT) & 7u;
       so[depth] = o, sd[depth] = d;
       depth++;
       V3 a = mk(u2f(lo.x), u2f(lo.y), u2f(lo.z));
+      if (hi.w & F_PRE_TRANSLATE) o = vsub(o, mk(u2f(lo.w), u2f(hi.x), u2f(hi.y)));  // the enclosing Translate, object.rs:275-278
       if (kind == XF_TRANSLATE) {
         o = vsub(o, a);                                  // object.rs:275-278
       } else if (kind == XF_ROTATE_Y) {
@@ -259,6 +302,7 @@ RT_DEV bool hit_top(const DevScene& sc, V3 o, V3 d, float time, float t_near, Sa
         } else if (kind == XF_FLIP) {
           rec.n = vneg(rec.n);                            // object.rs:249-252
         }                                                 // XF_MOVE: hit is NOT moved back (object.rs:504-511)
+        if (hi.w & F_PRE_TRANSLATE) rec.p = vadd(rec.p, mk(u2f(lo.w), u2f(hi.x), u2f(hi.y)));  // object.rs:279-282
         tag = depth;
       }
       o = so[depth], d = sd[depth];

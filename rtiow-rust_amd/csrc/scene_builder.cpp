@@ -272,6 +272,37 @@ static bool fuse_primitive(const SceneBuilder& b, uint32_t id, FlatScene* out, b
   }
 }
 
+// Is `id` exactly the And-tree rect_prism(p0, p1, material) builds (object.rs:420-473)?  Bit-compares
+// every Rect field, so anything else (different materials, hand-made boxes) stays six RECT records.
+static bool match_prism(const SceneBuilder& b, uint32_t id, float p0[3], float p1[3], uint32_t* mat) {
+  auto obj = [&](uint32_t i) -> const HostObject& { return b.objects[i]; };
+  auto is = [&](uint32_t i, HostObject::Kind k) { return i < b.objects.size() && obj(i).kind == k; };
+  if (!is(id, HostObject::AND)) return false;
+  const uint32_t pos = obj(id).a, neg = obj(id).b;
+  if (!is(pos, HostObject::AND) || !is(neg, HostObject::AND)) return false;
+  if (!is(obj(pos).b, HostObject::AND) || !is(obj(neg).b, HostObject::AND)) return false;
+  uint32_t face[6] = {obj(pos).a, obj(obj(pos).b).a, obj(obj(pos).b).b, obj(neg).a, obj(obj(neg).b).a, obj(obj(neg).b).b};
+  for (int i = 3; i < 6; i++) {
+    if (!is(face[i], HostObject::FLIP)) return false;
+    face[i] = obj(face[i]).a;
+  }
+  for (int i = 0; i < 6; i++)
+    if (!is(face[i], HostObject::RECT) || obj(face[i]).axis != 2 - (i % 3) || obj(face[i]).mat != obj(face[0]).mat) return false;
+  const HostObject &zp = obj(face[0]), &yp = obj(face[1]);
+  // Rect fields: f = (k, r0.start, r0.end, r1.start, r1.end)
+  p0[0] = zp.f[1], p1[0] = zp.f[2], p0[1] = zp.f[3], p1[1] = zp.f[4], p1[2] = zp.f[0], p0[2] = yp.f[3];
+  auto same = [](float a, float c) { return fbits(a) == fbits(c); };
+  for (int i = 0; i < 6; i++) {
+    const HostObject& r = obj(face[i]);
+    const int axis = 2 - (i % 3), a1 = axis == 0 ? 1 : 0, a2 = axis == 2 ? 1 : 2;
+    const float k = i < 3 ? p1[axis] : p0[axis];
+    if (!same(r.f[0], k) || !same(r.f[1], p0[a1]) || !same(r.f[2], p1[a1]) || !same(r.f[3], p0[a2]) || !same(r.f[4], p1[a2]))
+      return false;
+  }
+  *mat = zp.mat;
+  return true;
+}
+
 void SceneBuilder::emit_bvh(int32_t node_id, int depth, FlatScene* out, bool in_boundary) const {
   const HostBvhNode& n = bvh_nodes[node_id];
   size_t at = out->lo.size();
@@ -289,7 +320,15 @@ void SceneBuilder::emit(uint32_t id, bool under_bvh, bool and_in_bvh, int depth,
   const HostObject& o = objects[id];
   if (fuse_primitive(*this, id, out, true)) return;
   switch (o.kind) {
-    case HostObject::AND:
+    case HostObject::AND: {
+      float p0[3], p1[3];
+      uint32_t mat;
+      if (match_prism(*this, id, p0, p1, &mat)) {
+        push(out, p0[0], p1[0], p0[1], p1[1], fbits(p0[2]), fbits(p1[2]), mat, OP_PRISM | (materials[mat].kind << F_MATKIND_SHIFT));
+        out->features |= FEAT_RECT;
+        return;
+      }
+    }
       emit(o.a, under_bvh, under_bvh, depth, out, in_boundary);
       emit(o.b, under_bvh, under_bvh, depth, out, in_boundary);
       return;
@@ -333,11 +372,21 @@ void SceneBuilder::emit(uint32_t id, bool under_bvh, bool and_in_bvh, int depth,
   if (depth >= MAX_XFORM_DEPTH)
     throw BuildError{-5, "transform wrappers nested deeper than the kernel's ray stack (4)"};
   out->features |= FEAT_XFORM;
+  // Translate{RotateY{x}} / Translate{LinearMove{x}} (every transformed object of main.rs): one wrapper level
+  const HostObject* w = &o;
+  float pre[3] = {0, 0, 0};
+  uint32_t pre_flag = 0;
+  if (o.kind == HostObject::TRANSLATE && (objects[o.a].kind == HostObject::ROTATE_Y || objects[o.a].kind == HostObject::MOVE)) {
+    pre[0] = o.f[0], pre[1] = o.f[1], pre[2] = o.f[2];
+    pre_flag = F_PRE_TRANSLATE;
+    w = &objects[o.a];
+    kind = w->kind == HostObject::ROTATE_Y ? XF_ROTATE_Y : XF_MOVE;
+  }
   size_t at = out->lo.size();
-  push(out, o.f[0], o.f[1], o.f[2], 0, 0, 0, 0, OP_PUSH | (kind << F_KIND_SHIFT));
-  emit(o.a, under_bvh, and_in_bvh, depth + 1, out, in_boundary);
+  push(out, w->f[0], w->f[1], w->f[2], pre[0], fbits(pre[1]), fbits(pre[2]), 0, OP_PUSH | (kind << F_KIND_SHIFT) | pre_flag);
+  emit(w->a, under_bvh, and_in_bvh, depth + 1, out, in_boundary);
   out->hi[at].w[2] = (uint32_t)out->lo.size();
-  push(out, o.f[0], o.f[1], o.f[2], 0, 0, 0, (uint32_t)at, OP_POP | (kind << F_KIND_SHIFT));
+  push(out, w->f[0], w->f[1], w->f[2], pre[0], fbits(pre[1]), fbits(pre[2]), (uint32_t)at, OP_POP | (kind << F_KIND_SHIFT) | pre_flag);
 }
 
 void SceneBuilder::flatten(const uint32_t* world, size_t n, FlatScene* out) const {

@@ -10,7 +10,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-OP_END, OP_BOX, OP_SPHERE, OP_RECT, OP_PUSH, OP_POP, OP_MEDIUM = range(7)
+OP_END, OP_BOX, OP_SPHERE, OP_RECT, OP_PUSH, OP_POP, OP_MEDIUM, OP_PRISM = range(8)
 
 
 def header_symbols():
@@ -78,19 +78,37 @@ def test_flat_program_of_cornell_and_book2(pkg):
     world, _, _ = pkg.scenes.cornell_box_scene(b, 32, 32)
     words, feat = b.flatten(world)
     ops = (words[:, 7] & 0xff).tolist()
-    # 6 walls, then 2 x [PUSH translate, PUSH rotate, 6 rects, POP, POP]
-    assert ops == [OP_RECT] * 6 + ([OP_PUSH, OP_PUSH] + [OP_RECT] * 6 + [OP_POP, OP_POP]) * 2 + [OP_END]
+    # 6 walls, then 2 x [PUSH (Translate + RotateY in one wrapper level), PRISM, POP]
+    assert ops == [OP_RECT] * 6 + [OP_PUSH, OP_PRISM, OP_POP] * 2 + [OP_END]
     assert feat == (1 | 4)
-    # rect_prism order (object.rs:420-473): +Z, +Y, +X, then flipped -Z, -Y, -X
-    prism = words[8:14]
-    assert ((prism[:, 7] >> 10) & 3).tolist() == [2, 1, 0, 2, 1, 0]
-    assert ((prism[:, 7] >> 9) & 1).tolist() == [0, 0, 0, 1, 1, 1]
+    push = words[6]
+    assert (push[7] >> 8) & 7 == 1 and push[7] & (1 << 11)          # XF_ROTATE_Y | F_PRE_TRANSLATE
+    assert push[[3, 4, 5]].view(np.float32).tolist() == [130.0, 0.0, 65.0]
+    assert words[7, :6].view(np.float32).tolist() == [0.0, 165.0, 0.0, 165.0, 0.0, 165.0]   # (p0.x, p1.x, p0.y, p1.y, p0.z, p1.z)
+    # an And-tree that is NOT rect_prism's (here: one face of another material) stays six RECT records,
+    # in rect_prism's order (object.rs:420-473): +Z, +Y, +X, then flipped -Z, -Y, -X
+    m1, m2 = b.lambertian(b.constant(pkg.scenes.vfrom(0.5))), b.lambertian(b.constant(pkg.scenes.vfrom(0.25)))
+    p0, p1 = (0.0, 0.0, 0.0), (1.0, 2.0, 3.0)
+    faces = [b.rect(2, (p0[0], p1[0]), (p0[1], p1[1]), p1[2], m1), b.rect(1, (p0[0], p1[0]), (p0[2], p1[2]), p1[1], m1),
+             b.rect(0, (p0[1], p1[1]), (p0[2], p1[2]), p1[0], m1),
+             b.flip_normals(b.rect(2, (p0[0], p1[0]), (p0[1], p1[1]), p0[2], m1)),
+             b.flip_normals(b.rect(1, (p0[0], p1[0]), (p0[2], p1[2]), p0[1], m1)),
+             b.flip_normals(b.rect(0, (p0[1], p1[1]), (p0[2], p1[2]), p0[0], m2))]
+    odd = b.and_(b.and_(faces[0], b.and_(faces[1], faces[2])), b.and_(faces[3], b.and_(faces[4], faces[5])))
+    prism, _ = b.flatten([odd])
+    assert (prism[:, 7] & 0xff).tolist() == [OP_RECT] * 6 + [OP_END]
+    assert ((prism[:6, 7] >> 10) & 3).tolist() == [2, 1, 0, 2, 1, 0]
+    assert ((prism[:6, 7] >> 9) & 1).tolist() == [0, 0, 0, 1, 1, 1]
+    same = b.and_(b.and_(faces[0], b.and_(faces[1], faces[2])),
+                  b.and_(faces[3], b.and_(faces[4], b.flip_normals(b.rect(0, (p0[1], p1[1]), (p0[2], p1[2]), p0[0], m1)))))
+    assert (b.flatten([same])[0][:, 7] & 0xff).tolist() == [OP_PRISM, OP_END]
     b = be.builder()
     world, _, _ = pkg.scenes.book_final_scene(b, 32, 32, pkg.small_rng.SmallRng(0xDEADBEEF))
     words, feat = b.flatten(world)
     ops = words[:, 7] & 0xff
     assert feat == 15
-    assert int((ops == OP_MEDIUM).sum()) == 2 and int((ops == OP_RECT).sum()) == 400 * 6 + 1
+    assert int((ops == OP_MEDIUM).sum()) == 2 and int((ops == OP_RECT).sum()) == 1 and int((ops == OP_PRISM).sum()) == 400
+    assert int((ops == OP_PUSH).sum()) == 2               # Translate{LinearMove{Sphere}}, Translate{RotateY{Bvh}}: one level each
     assert int((ops == OP_BOX).sum()) == (2 * 400 - 1) + (2 * 1000 - 1)
     med = np.nonzero(ops == OP_MEDIUM)[0]
     assert (ops[med + 1] == OP_SPHERE).all()            # boundary record follows its medium
