@@ -80,6 +80,8 @@ struct PoolTuning {
   uint32_t refill_min;   // idle lanes before the wave services (finish / shade / refill)
   uint32_t sphere_min;   // parked lanes before a sphere pass
   uint32_t box_leave;    // lanes leaving the BOX state before a box run re-evaluates the schedule
+  uint32_t run_ahead;    // full-feature kernel: records a slow pass may execute per lane ...
+  uint32_t run_ahead_min;  // ... while at least this many lanes sit on slow records
 };
 
 // LDS image of the program (staged variant): one 48-byte record per instruction, pc = 48 r.

@@ -361,8 +361,13 @@ __global__ __launch_bounds__(512) void render_full_pool(DevScene sc, DevCamera c
       } while (n_now > floor_lanes);
       if (COUNT) t_box += RT_TICK() - t_mark;
     } else if (b_slow != 0) {
-      // ---- slow pass: every parked lane executes ONE record ----
-      if (COUNT) n_slow_it++, n_slow_lanes += (uint32_t)__builtin_popcountll(b_slow), t_mark = RT_TICK();
+      // ---- slow pass: every parked lane executes one record, then runs ahead through up to
+      // `run_ahead` - 1 more while enough lanes still sit on slow records (the objects of a list world
+      // are visited in the same order by every ray, so these lanes mostly share their next kinds) ----
+      if (COUNT) t_mark = RT_TICK();
+#pragma unroll 1
+      for (uint32_t ahead = 0;; ahead++) {
+      if (COUNT) n_slow_it++, n_slow_lanes += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op >= OP_SPHERE && op <= OP_PRISM));
       if (op == OP_SPHERE) {  // Sphere::hit, object.rs:84-111 (+ fused Translate / FlipNormals)
         if (COUNT) cnt.prim++;
         const V3 off = mk(u2f(cur_lo.x), u2f(cur_lo.y), u2f(cur_lo.z));
@@ -468,7 +473,10 @@ __global__ __launch_bounds__(512) void render_full_pool(DevScene sc, DevCamera c
         }
         pc = cur_hi.x;  // first record after the boundary's stream
       }
-      if (op >= OP_SPHERE && op <= OP_PRISM) cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc);
+      if (op >= OP_SPHERE && op <= OP_PRISM) cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc), op = cur_hi.w & 0xffu;
+      if (ahead + 1u >= tune.run_ahead) break;
+      if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op >= OP_SPHERE && op <= OP_PRISM)) < tune.run_ahead_min) break;
+      }
       if (COUNT) t_slow += RT_TICK() - t_mark;
     }
   }
