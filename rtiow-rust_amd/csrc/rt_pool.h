@@ -191,6 +191,8 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
   uint32_t t_count = 0, s_count = 0, e_count = POOL, n_dead = 0;  // wave-uniform list sizes / retired slots
   uint32_t w_next = 0, w_end = 0;                                  // this wave's reserved range of work items
   bool exhausted = false;                                          // the global counter ran past total_work
+  const unsigned long long t_start = RT_TICK();
+  unsigned long long t_exhausted = 0;
 
   // ---- per-lane traversal state ---------------------------------------------------------------
   uint32_t my_slot = 0;
@@ -426,6 +428,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
             base = __builtin_amdgcn_readfirstlane(base);
             if (base >= total_work) {
               exhausted = true;
+              if (COUNT) t_exhausted = RT_TICK();
             } else {
               w_next = base;
               w_end = (total_work - base < WORK_BLOCK) ? total_work : base + WORK_BLOCK;
@@ -558,6 +561,10 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
       atomicAdd(&counters[16], t_shade), atomicAdd(&counters[17], t_serv - t_shade), atomicAdd(&counters[18], t_box),
           atomicAdd(&counters[19], t_sph);
       atomicAdd(&counters[20], (unsigned long long)n_end), atomicAdd(&counters[21], (unsigned long long)n_end_lanes);
+      // wave timeline (s_memtime is not synchronised across XCDs: only per-wave differences are meaningful)
+      const unsigned long long dur = RT_TICK() - t_start, exh = t_exhausted - t_start;
+      atomicMax(&counters[24], dur), atomicAdd(&counters[25], dur), atomicAdd(&counters[26], 1ull);
+      atomicMax(&counters[27], (1ull << 62) - exh), atomicAdd(&counters[28], exh), atomicMax(&counters[29], exh);
     }
   }
 #undef RT_BOX_STEP

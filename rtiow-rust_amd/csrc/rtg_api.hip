@@ -711,7 +711,7 @@ int rtg_scene_create(rtg_builder* b, const rtg_id* world, size_t n, int device, 
   if (const char* kv = getenv("RTG_RUN_AHEAD")) s->pool_tune.run_ahead = (uint32_t)atoi(kv);
   if (const char* kv = getenv("RTG_RUN_AHEAD_MIN")) s->pool_tune.run_ahead_min = (uint32_t)atoi(kv);
   if (const char* kv = getenv("RTG_SPHERE_MIN")) s->pool_tune.sphere_min = (uint32_t)atoi(kv);
-  if (hipMalloc((void**)&s->d_counters, 24 * sizeof(unsigned long long)) != hipSuccess ||
+  if (hipMalloc((void**)&s->d_counters, 32 * sizeof(unsigned long long)) != hipSuccess ||
       hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
     rtg_scene_destroy(s);
     return fail(RTG_ERR_DEVICE, "scene: counter/event allocation failed");
@@ -786,7 +786,7 @@ int rtg_par_cast_device(rtg_scene* s, const rtg_camera* camera, const rtg_params
   bool count = stats && (params->flags & RTG_FLAG_COUNTERS);
   if (count) {
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, 7 * sizeof(unsigned long long), stream));
-    HIP_TRY(hipMemsetAsync(s->d_counters + 8, 0, 16 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(s->d_counters + 8, 0, 24 * sizeof(unsigned long long), stream));
   }
   if (stats) HIP_TRY(hipEventRecord(s->ev0, stream));
   HIP_TRY(count ? launch_render<true>(s, cam, d, d_out, stream) : launch_render<false>(s, cam, d, d_out, stream));
@@ -801,8 +801,13 @@ int rtg_par_cast_device(rtg_scene* s, const rtg_camera* camera, const rtg_params
     if (count) HIP_TRY(hipMemcpy(h, s->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     stats->aabb_tests = h[0], stats->prim_tests = h[1], stats->shaded_hits = h[2], stats->rays = h[3], stats->draws = h[4];
     if (count && getenv("RTG_VERBOSE")) {
-      unsigned long long q[16];
+      unsigned long long q[24];
       HIP_TRY(hipMemcpy(q, s->d_counters + 8, sizeof(q), hipMemcpyDeviceToHost));
+      if (q[18]) {  // lean pool kernel: per-wave timeline, scaled so that the longest wave = the measured kernel time
+        const double us = (double)ms * 1000. / (double)q[16], n = (double)q[18];
+        fprintf(stderr, "[rtg] wave timeline (us from its start): sees the work queue empty at min %.0f / mean %.0f / max %.0f; done at mean %.0f / max %.0f\n",
+                (double)((1ull << 62) - q[19]) * us, (double)q[20] / n * us, (double)q[21] * us, (double)q[17] / n * us, (double)q[16] * us);
+      }
       double tt = (double)(q[8] + q[9] + q[10] + q[11]);
       fprintf(stderr, "[rtg] wave-time shares (s_memtime, instrumented variant): shade %.1f%% gen+pull|service %.1f%% box %.1f%% sphere %.1f%%; "
               "per pass: shade %.0f, gen|service %.0f, box %.0f, sphere %.0f ticks\n", 100 * q[8] / tt, 100 * q[9] / tt, 100 * q[10] / tt,
