@@ -45,8 +45,12 @@ __device__ __attribute__((noinline)) float event_draw_f32(uint64_t seed, uint32_
 // PROG: 0 = program fetched from global memory (L1/L2), 1 = whole program staged in LDS, 2 = an LDS
 // window over the first `window` records (depth-first order, so it holds whole leading subtrees: book-2's
 // 199 KB program keeps its floor Bvh and most top-level objects in LDS) and global memory for the rest.
+#ifndef RT_FULL_TEX_THREADS
+#define RT_FULL_TEX_THREADS 1024  // the textured variant wants ~142 VGPRs; capped at 128 it spills ~25 of them to scratch but
+                                  // runs 16 instead of 12 waves per CU: measured 4 % faster on book-2 (768 = no spills)
+#endif
 template <int PROG, bool TEX, bool COUNT>
-__global__ __launch_bounds__(512) void render_full_pool(DevScene sc, DevCamera cam, DevParams P, float* __restrict__ out,
+__global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_pool(DevScene sc, DevCamera cam, DevParams P, float* __restrict__ out,
                                                         uint32_t total_work, uint32_t* __restrict__ queue,
                                                         unsigned long long* counters, PoolTuning tune, ChunkMode cm,
                                                         uint32_t* __restrict__ g_slots, float* __restrict__ g_stack,

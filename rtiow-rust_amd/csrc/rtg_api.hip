@@ -169,6 +169,7 @@ struct rtg_scene {
   PoolTuning pool_tune{20, 16, 32, 12, 16};
   Tuning tune{24, 16, 8};
   int block_threads = 512, wg_per_cu = 0;  // 0 = ask the occupancy API
+  int full_threads = 0;                    // full-feature pool kernel: 0 = the variant's maximum (RTG_BLOCK overrides)
   int pool_threads = 1024;                 // lean ray-pool kernel: ONE 16-wave workgroup per CU shares one LDS copy of the program
 };
 
@@ -315,7 +316,9 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
   if (total_work > 0xfffffffeull || (scratch_need > s->scratch_bytes && scratch_need > scratch_cap())) return hipErrorNotSupported;
   if (pix_work == 0) return hipSuccess;
   const bool tex = (s->features & FEAT_TEXTURE) != 0;
-  const int bt = s->block_threads;
+  // ONE 16-wave workgroup per CU shares one LDS copy of the program (128 VGPRs per lane).
+  const int bt_max = tex ? RT_FULL_TEX_THREADS : 1024;
+  const int bt = s->full_threads > 0 && s->full_threads <= bt_max ? s->full_threads : bt_max;
   const uint32_t waves = (uint32_t)bt / 64;
   hipError_t e = grow((void**)&s->d_scratch, &s->scratch_bytes, scratch_need);
   if (e != hipSuccess) return e;
@@ -323,17 +326,13 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
   uint32_t* queue = (uint32_t*)(s->d_counters + 7);
   e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
-  // Program placement.  The untextured variant fits 128 VGPRs (two 512-thread workgroups per CU): stage the
-  // program when it fits beside a second workgroup (72 KB each).  The textured variant needs ~145 VGPRs, so
-  // only one workgroup is resident per CU and it may use ~150 KB of LDS: whole program or a leading window.
+  // Program placement: the whole program in LDS when it fits beside the lists, else a leading window
+  // (depth-first order: the window holds whole leading subtrees) and global memory for the rest.
   const size_t list_bytes = full_pool_lds_bytes(0, waves);
-  const size_t budget = tex ? 150 * 1024 : 72 * 1024;
+  const size_t budget = 158 * 1024;
   uint32_t window = s->n_prog;
   int prog = 1;
-  if ((size_t)window * 32 + list_bytes > budget) {
-    if (tex) window = (uint32_t)((budget - list_bytes) / 32), prog = 2;
-    else window = 0, prog = 0;
-  }
+  if ((size_t)window * 32 + list_bytes > budget) window = (uint32_t)((budget - list_bytes) / 32), prog = 2;
   if (const char* kv = getenv("RTG_WINDOW")) {
     window = std::min<uint32_t>(s->n_prog, (uint32_t)atoi(kv));
     prog = window == 0 ? 0 : (window == s->n_prog ? 1 : 2);
@@ -702,7 +701,7 @@ int rtg_scene_create(rtg_builder* b, const rtg_id* world, size_t n, int device, 
   if (s->num_cus <= 0) s->num_cus = 256;
   if (const char* kv = getenv("RTG_KERNEL")) s->kernel_version = atoi(kv);  // A/B switches for measurements
   if (const char* kv = getenv("RTG_CHUNKS")) s->force_chunks = atoi(kv);
-  if (const char* kv = getenv("RTG_BLOCK")) s->block_threads = s->pool_threads = atoi(kv);
+  if (const char* kv = getenv("RTG_BLOCK")) s->block_threads = s->pool_threads = s->full_threads = atoi(kv);
   if (const char* kv = getenv("RTG_WG_PER_CU")) s->wg_per_cu = atoi(kv);
   if (const char* kv = getenv("RTG_REGEN_MIN")) s->tune.regen_min = (uint32_t)atoi(kv);
   if (const char* kv = getenv("RTG_SPHERE_MIN")) s->tune.sphere_min = (uint32_t)atoi(kv);
