@@ -453,24 +453,24 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         // baseline kernel by the host: the nested boundary walk would cost every scene ~20 VGPRs here)
         const uint4 blo = RT_FETCH_LO(pc + 16u), bhi = RT_FETCH_HI(pc + 16u);
         float t1, t2;
-        if (COUNT) cnt.prim++;
-        if (prim_hit_t(blo, bhi, o, d, -F32_MAX, F32_MAX, t1)) {
-          if (COUNT) cnt.prim++;
-          if (prim_hit_t(blo, bhi, o, d, t1 + 0.0001f, F32_MAX, t2)) {
-            t1 = rs_max(t1, t_near);
-            t2 = rs_min(t2, best);
-            if (!(t1 >= t2)) {
-              float distance_inside = (t2 - t1) * vlen(d);
-              float hit_distance = -(1.f / u2f(cur_lo.x)) * rt_logf(event_draw_f32(seed, r_pixel, r_sample, r_event, ev_draws));
-              ev_draws++;
-              if (COUNT) total_draws++;
-              if (hit_distance < distance_inside) {
-                float t = t1 + hit_distance / vlen(d);
-                bool accept = !(cur_hi.w & F_UNDER_BVH) || nhits == root_hits || !(best < t);
-                if (accept) {
-                  hp = vadd(o, smul(t, d)), hn = mk(1.f, 0.f, 0.f), hmat = cur_hi.z;
-                  best = t, tag = depth, nhits++;
-                }
+        uint32_t n_tests;
+        const bool crossed = boundary_pair_t(blo, bhi, o, d, t1, t2, n_tests);
+        if (COUNT) cnt.prim += n_tests;
+        if (crossed) {
+          t1 = rs_max(t1, t_near);
+          t2 = rs_min(t2, best);
+          if (!(t1 >= t2)) {
+            const float len = vlen(d);
+            float distance_inside = (t2 - t1) * len;
+            float hit_distance = -(1.f / u2f(cur_lo.x)) * rt_logf(event_draw_f32(seed, r_pixel, r_sample, r_event, ev_draws));
+            ev_draws++;
+            if (COUNT) total_draws++;
+            if (hit_distance < distance_inside) {
+              float t = t1 + hit_distance / len;
+              bool accept = !(cur_hi.w & F_UNDER_BVH) || nhits == root_hits || !(best < t);
+              if (accept) {
+                hp = vadd(o, smul(t, d)), hn = mk(1.f, 0.f, 0.f), hmat = cur_hi.z;
+                best = t, tag = depth, nhits++;
               }
             }
           }

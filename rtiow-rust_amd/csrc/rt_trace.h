@@ -116,6 +116,37 @@ RT_DEV bool prim_hit_t(uint4 lo, uint4 hi, V3 o, V3 d, float t0, float t1, float
                     u2f(hi.x), t0, t1, t);
 }
 
+// ConstantMedium's two boundary queries (object.rs:551-552) against ONE primitive record:
+//   h1 = boundary.hit(ray, f32::MIN..f32::MAX);  h2 = boundary.hit(ray, h1.t + 0.0001..f32::MAX)
+// For a sphere both calls evaluate the same a, b, c, discriminant and roots (Sphere::hit is a pure function
+// of the ray); only the accepted range differs, so the roots are computed once and the range predicates
+// of object.rs:99 are applied twice.  Returns true when both queries hit.
+RT_DEV bool boundary_pair_t(uint4 lo, uint4 hi, V3 o, V3 d, float& t1, float& t2, uint32_t& n_tests) {
+  n_tests = 1;
+  if ((hi.w & 0xffu) != OP_SPHERE) {
+    if (!prim_hit_t(lo, hi, o, d, -F32_MAX, F32_MAX, t1)) return false;
+    n_tests = 2;
+    return prim_hit_t(lo, hi, o, d, t1 + 0.0001f, F32_MAX, t2);
+  }
+  V3 c = o;
+  if (hi.w & F_TRANSLATE) c = vsub(o, mk(u2f(lo.x), u2f(lo.y), u2f(lo.z)));
+  const float radius = u2f(lo.w);
+  const float a = vdot(d, d), b = vdot(c, d), cc = vdot(c, c) - radius * radius;
+  const float disc = b * b - a * cc;
+  if (!(disc > 0.f)) return false;
+  const float sq = __builtin_sqrtf(disc);
+  const float r1 = (-b - sq) / a, r2 = (-b + sq) / a;
+  if (r1 < F32_MAX && r1 >= -F32_MAX) t1 = r1;
+  else if (r2 < F32_MAX && r2 >= -F32_MAX) t1 = r2;
+  else return false;
+  n_tests = 2;
+  const float lo2 = t1 + 0.0001f;
+  if (r1 < F32_MAX && r1 >= lo2) t2 = r1;
+  else if (r2 < F32_MAX && r2 >= lo2) t2 = r2;
+  else return false;
+  return true;
+}
+
 // `boundary.hit(ray, t_lo..t_hi)` of ConstantMedium (object.rs:551-552) when the boundary is an object graph:
 // a nested walk over the boundary's own records [first, end) that only keeps the closest t.  Same
 // predicates and visiting order as hit_top; no hit record, no media.  Rare path -> out of line, program
