@@ -47,6 +47,8 @@ constexpr uint32_t F_AXIS_SHIFT = 10;       // RECT: bits 10-11 = orthogonal axi
 constexpr uint32_t F_UNDER_BVH = 1u << 12;  // MEDIUM: lives below a Bvh node (hit-merge rule of bvh.rs:104-112)
 constexpr uint32_t F_BVH_ROOT = 1u << 13;   // BOX: root of an outermost Bvh (a Bvh not nested below another Bvh)
 constexpr uint32_t F_GENERAL_BOUNDARY = 1u << 14;  // MEDIUM: the boundary is an object graph (several records), not one primitive
+constexpr uint32_t F_GATHER = 1u << 15;     // any non-BOX record: head of a run of >= 4 list-level records without a Bvh (scheduling
+                                            // hint: every ray passes here and then executes the same records in the same order)
 constexpr uint32_t F_MATKIND_SHIFT = 16;    // SPHERE/RECT/MEDIUM: bits 16-18 = MatKind of the record's material (copy, for schedulers)
 constexpr uint32_t F_KIND_SHIFT = 8;        // PUSH/POP: bits 8-10 = XformKind
 constexpr uint32_t F_PRE_TRANSLATE = 1u << 11;  // PUSH/POP (RotateY / LinearMove): an enclosing Translate rides along,

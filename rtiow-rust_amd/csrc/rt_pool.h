@@ -82,6 +82,7 @@ struct PoolTuning {
   uint32_t box_leave;    // lanes leaving the BOX state before a box run re-evaluates the schedule
   uint32_t run_ahead;    // full-feature kernel: records a slow pass may execute per lane ...
   uint32_t run_ahead_min;  // ... while at least this many lanes sit on slow records
+  uint32_t gather_min;   // full-feature kernel: lanes waiting at an F_GATHER record before they are released together
 };
 
 // LDS image of the program (staged variant): one 48-byte record per instruction, pc = 48 r.

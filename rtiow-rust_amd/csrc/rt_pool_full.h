@@ -337,7 +337,16 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
     }
     // ============================== TRAVERSE ======================================================
     const uint64_t b_box = __builtin_amdgcn_ballot_w64(op == OP_BOX);
-    const uint64_t b_slow = __builtin_amdgcn_ballot_w64(op >= OP_SPHERE && op <= OP_PRISM);
+    // Lanes at a gather point (head of a list-level run of records every ray executes in the same order)
+    // are held until `gather_min` of them wait there -- or nothing else can run -- and then walk the run
+    // together: one record kind per iteration, many lanes wide, instead of a few lanes per kind.
+    const bool is_slow = op >= OP_SPHERE && op <= OP_PRISM;
+    const bool at_gather = is_slow && (cur_hi.w & F_GATHER) != 0u;
+    const uint64_t b_gather = __builtin_amdgcn_ballot_w64(at_gather);
+    const bool release = (uint32_t)__builtin_popcountll(b_gather) >= tune.gather_min ||
+                         (b_box == 0 && __builtin_amdgcn_ballot_w64(is_slow && !at_gather) == 0);
+    const bool runnable = is_slow && (!at_gather || release);
+    const uint64_t b_slow = __builtin_amdgcn_ballot_w64(runnable);
     if (b_box != 0 && (uint32_t)__builtin_popcountll(b_slow) < tune.sphere_min) {
       const uint32_t n0 = (uint32_t)__builtin_popcountll(b_box);
       const uint32_t floor_lanes = n0 > tune.box_leave ? n0 - tune.box_leave : 0u;
@@ -369,6 +378,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
       // `run_ahead` - 1 more while enough lanes still sit on slow records (the objects of a list world
       // are visited in the same order by every ray, so these lanes mostly share their next kinds) ----
       if (COUNT) t_mark = RT_TICK();
+      if (!runnable) op = 0xfeu;  // held at a gather point: sits this pass out
 #pragma unroll 1
       for (uint32_t ahead = 0;; ahead++) {
       if (COUNT) n_slow_it++, n_slow_lanes += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op >= OP_SPHERE && op <= OP_PRISM));
@@ -477,7 +487,10 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         }
         pc = cur_hi.x;  // first record after the boundary's stream
       }
-      if (op >= OP_SPHERE && op <= OP_PRISM) cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc), op = cur_hi.w & 0xffu;
+      if (op >= OP_SPHERE && op <= OP_PRISM) {
+        cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc), op = cur_hi.w & 0xffu;
+        if ((cur_hi.w & F_GATHER) && !release) op = 0xfeu;  // arrived at a gather point: wait for the next batch
+      }
       if (ahead + 1u >= tune.run_ahead) break;
       if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op >= OP_SPHERE && op <= OP_PRISM)) < tune.run_ahead_min) break;
       }

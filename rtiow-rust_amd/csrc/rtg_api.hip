@@ -166,7 +166,7 @@ struct rtg_scene {
   // lean scenes: 3 = ray-pool kernel (rt_pool.h), 2 = persistent single-wave regeneration (rt_persistent.h),
   // 1 = one-lane-per-pixel baseline (rt_trace.h).  Non-lean scenes always use 1.
   int kernel_version = 3;
-  PoolTuning pool_tune{20, 16, 32, 12, 16};
+  PoolTuning pool_tune{20, 16, 32, 16, 16, 40};
   Tuning tune{24, 16, 8};
   int block_threads = 512, wg_per_cu = 0;  // 0 = ask the occupancy API
   int full_threads = 0;                    // full-feature pool kernel: 0 = the variant's maximum (RTG_BLOCK overrides)
@@ -707,6 +707,7 @@ int rtg_scene_create(rtg_builder* b, const rtg_id* world, size_t n, int device, 
   if (const char* kv = getenv("RTG_SPHERE_MIN")) s->tune.sphere_min = (uint32_t)atoi(kv);
   if (const char* kv = getenv("RTG_BOX_LEAVE")) s->tune.box_leave = s->pool_tune.box_leave = (uint32_t)atoi(kv);
   if (const char* kv = getenv("RTG_REFILL_MIN")) s->pool_tune.refill_min = (uint32_t)atoi(kv);
+  if (const char* kv = getenv("RTG_GATHER_MIN")) s->pool_tune.gather_min = (uint32_t)atoi(kv);
   if (const char* kv = getenv("RTG_RUN_AHEAD")) s->pool_tune.run_ahead = (uint32_t)atoi(kv);
   if (const char* kv = getenv("RTG_RUN_AHEAD_MIN")) s->pool_tune.run_ahead_min = (uint32_t)atoi(kv);
   if (const char* kv = getenv("RTG_SPHERE_MIN")) s->pool_tune.sphere_min = (uint32_t)atoi(kv);

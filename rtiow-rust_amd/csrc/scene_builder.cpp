@@ -392,10 +392,27 @@ void SceneBuilder::emit(uint32_t id, bool under_bvh, bool and_in_bvh, int depth,
 void SceneBuilder::flatten(const uint32_t* world, size_t n, FlatScene* out) const {
   out->lo.clear(), out->hi.clear(), out->mat.clear(), out->tex.clear();
   out->features = 0;
+  // Runs of consecutive list-level objects that hold no Bvh are straight-line code every ray executes in
+  // the same order: their first record is marked F_GATHER so a scheduler can batch the rays there.
+  size_t run_start = 0;
+  bool in_run = false;
+  auto close_run = [&](size_t end) {
+    if (in_run && end - run_start >= 4) out->hi[run_start].w[3] |= F_GATHER;
+    in_run = false;
+  };
   for (size_t i = 0; i < n; i++) {
     if (world[i] >= objects.size()) throw BuildError{-1, "scene: bad world object handle"};
+    const size_t at = out->lo.size();
     emit(world[i], false, false, 0, out);
+    bool has_box = false;
+    for (size_t r = at; r < out->lo.size(); r++) has_box |= (out->hi[r].w[3] & 0xffu) == OP_BOX;
+    if (has_box) {
+      close_run(at);
+    } else if (!in_run) {
+      in_run = true, run_start = at;
+    }
   }
+  close_run(out->lo.size());
   push(out, 0, 0, 0, 0, 0, 0, 0, OP_END);
   for (const HostMaterial& m : materials) {
     float c[3] = {m.albedo[0], m.albedo[1], m.albedo[2]};
