@@ -50,6 +50,7 @@ constexpr uint32_t F_GENERAL_BOUNDARY = 1u << 14;  // MEDIUM: the boundary is an
 constexpr uint32_t F_GATHER = 1u << 15;     // any non-BOX record: head of a run of >= 4 list-level records without a Bvh (scheduling
                                             // hint: every ray passes here and then executes the same records in the same order)
 constexpr uint32_t F_MATKIND_SHIFT = 16;    // SPHERE/RECT/MEDIUM: bits 16-18 = MatKind of the record's material (copy, for schedulers)
+constexpr uint32_t F_TEXTURED = 1u << 19;   // SPHERE/RECT/PRISM/MEDIUM: the material reads a checker / Perlin texture (copy, for schedulers)
 constexpr uint32_t F_KIND_SHIFT = 8;        // PUSH/POP: bits 8-10 = XformKind
 constexpr uint32_t F_PRE_TRANSLATE = 1u << 11;  // PUSH/POP (RotateY / LinearMove): an enclosing Translate rides along,
                                                 // offset = (lo.w, hi.x, hi.y): applied first on the way in, last on the way out

@@ -27,7 +27,7 @@ enum FullPoolField : uint32_t {
 
 // LDS = the first `window` program records (all of them when the program fits, 0 = none) + the lists
 inline size_t full_pool_lds_bytes(uint32_t window, uint32_t waves) {
-  return (size_t)window * 32 + (size_t)waves * POOL * 2 * 4;
+  return (size_t)window * 32 + (((size_t)waves * POOL * 3 * 2 + 15) & ~(size_t)15);  // T-, S- and X-list (u16 slot ids)
 }
 
 // draw `idx` (0-based) of the stream (seed, pixel, sample, event): word idx%4 of Philox block idx/4
@@ -80,19 +80,20 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   uint32_t* slot = g_slots + gwave * (POOL * FPOOL_FIELDS);
   float* slotf = reinterpret_cast<float*>(slot);
   float* stack = g_stack + gwave * (MAX_XFORM_DEPTH * 6 * 64);  // [level][component][lane]
-  uint32_t* tlist = reinterpret_cast<uint32_t*>(s_mem + staged) + wave * (2u * POOL);
-  uint32_t* slist = tlist + POOL;
+  uint16_t* tlist = reinterpret_cast<uint16_t*>(s_mem + staged) + wave * (3u * POOL);
+  uint16_t* slist = tlist + POOL;  // finished rays whose material needs no texture lookup (and slots without a ray)
+  uint16_t* xlist = slist + POOL;  // finished rays that hit a checker / Perlin textured material
 #define SLOT_U(f_, j_) slot[(f_)*POOL + (j_)]
 #define SLOT_F(f_, j_) slotf[(f_)*POOL + (j_)]
   for (uint32_t j = lane; j < POOL; j += 64u) {
     SLOT_U(FF_HITMAT, j) = SLOT_NEED_PIXEL;
-    slist[j] = j;
+    slist[j] = (uint16_t)j;
   }
   __syncthreads();
 
   const uint64_t seed = ((uint64_t)P.seed_hi << 32) | P.seed_lo;
   const float t_near = P.t_near;
-  uint32_t t_count = 0, s_count = POOL, n_dead = 0;
+  uint32_t t_count = 0, s_count = POOL, x_count = 0, n_dead = 0;
   uint32_t w_next = 0, w_end = 0;
   bool exhausted = false;
 
@@ -122,29 +123,37 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
       if (COUNT) t_mark = RT_TICK();
       {  // (1) finish
         const bool fin = have_ray && op == OP_END;
-        const uint64_t m_fin = __builtin_amdgcn_ballot_w64(fin);
+        // hmat bit 31 = the hit material reads a non-constant texture (F_TEXTURED of the winning record):
+        // such hits are shaded in their own passes, so the Perlin / checker code is issued for 64 textured
+        // hits at a time instead of in every pass that happens to hold one
+        const bool to_x = TEX && fin && hmat != NO_HIT && (hmat >> 31) != 0u;
+        const uint64_t m_fin = __builtin_amdgcn_ballot_w64(fin && !to_x), m_x = __builtin_amdgcn_ballot_w64(to_x);
         if (fin) {
-          SLOT_U(FF_HITMAT, my_slot) = hmat;
+          SLOT_U(FF_HITMAT, my_slot) = hmat == NO_HIT ? NO_HIT : (hmat & 0x7fffffffu);
           SLOT_F(FF_P, my_slot) = hp.x, SLOT_F(FF_P + 1, my_slot) = hp.y, SLOT_F(FF_P + 2, my_slot) = hp.z;
           SLOT_F(FF_N, my_slot) = hn.x, SLOT_F(FF_N + 1, my_slot) = hn.y, SLOT_F(FF_N + 2, my_slot) = hn.z;
           SLOT_U(FF_EVDRAWS, my_slot) = ev_draws;
-          slist[s_count + lane_rank(m_fin)] = my_slot;
+          if (to_x) xlist[x_count + lane_rank(m_x)] = (uint16_t)my_slot;
+          else slist[s_count + lane_rank(m_fin)] = (uint16_t)my_slot;
           have_ray = false;
         }
         s_count += (uint32_t)__builtin_popcountll(m_fin);
+        x_count += (uint32_t)__builtin_popcountll(m_x);
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       // (2) shade
-      while (s_count >= 64u || (s_count > 0 && t_count == 0 && n_busy == 0)) {
-        const uint32_t take = s_count < 64u ? s_count : 64u;
-        s_count -= take;
+      auto shade_pass = [&](auto textured_tag, uint16_t* list, uint32_t& count) {
+        constexpr bool TEXTURED = decltype(textured_tag)::value;
+        constexpr uint32_t PASS_FEAT = TEXTURED ? FEAT : (FEAT & ~FEAT_TEXTURE);
+        const uint32_t take = count < 64u ? count : 64u;
+        count -= take;
         if (COUNT) n_shade++, n_shade_lanes += take, t_mark2 = RT_TICK();
         uint32_t st = ST_DEAD, j = 0;
         V3 so = mk(0.f, 0.f, 0.f), sd = so, strength = so, accum = so;
         float stime = 0.f;
         uint32_t bounces = 0, s = 0, x = 0, row = 0;
         if (lane < take) {
-          j = slist[s_count + lane];
+          j = list[count + lane];
           const uint32_t hm = SLOT_U(FF_HITMAT, j);
           if (hm == SLOT_NEED_PIXEL) {
             st = ST_NEED_PIXEL;
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
             V3 texval = mk(0.f, 0.f, 0.f);
             if (hm != NO_HIT) {
               mlo = sc.mat[2 * hm], mhi = sc.mat[2 * hm + 1];
-              texval = material_texture<FEAT>(sc, mlo, mhi, p);  // = albedo / emission colour for constant textures
+              texval = material_texture<PASS_FEAT>(sc, mlo, mhi, p);  // = albedo / emission colour for constant textures
             }
             so = mk(SLOT_F(FF_O, j), SLOT_F(FF_O + 1, j), SLOT_F(FF_O + 2, j));
             sd = mk(SLOT_F(FF_D, j), SLOT_F(FF_D + 1, j), SLOT_F(FF_D + 2, j));
@@ -297,14 +306,18 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           SLOT_F(FF_ACCUM, j) = accum.x, SLOT_F(FF_ACCUM + 1, j) = accum.y, SLOT_F(FF_ACCUM + 2, j) = accum.z;
           SLOT_U(FF_BOUNCES, j) = bounces, SLOT_U(FF_SAMPLE, j) = s;
           SLOT_U(FF_XY, j) = x | (row << 16);
-          tlist[t_count + lane_rank(m_live)] = j;
+          tlist[t_count + lane_rank(m_live)] = (uint16_t)j;
           if (COUNT) cnt.rays++;
         }
         t_count += (uint32_t)__builtin_popcountll(m_live);
         n_dead += take - (uint32_t)__builtin_popcountll(m_live);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         if (COUNT) t_shade += RT_TICK() - t_mark2;
-      }
+      };
+      const bool starving = t_count == 0 && n_busy == 0;
+      while (s_count >= 64u || (s_count > 0 && starving)) shade_pass(std::false_type{}, slist, s_count);
+      if (TEX)
+        while (x_count >= 64u || (x_count > 0 && starving && t_count == 0)) shade_pass(std::true_type{}, xlist, x_count);
       {  // (3) refill
         const uint64_t m_idle = __builtin_amdgcn_ballot_w64(!have_ray);
         const uint32_t n_idle = (uint32_t)__builtin_popcountll(m_idle);
@@ -393,7 +406,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           V3 n = sdiv(p, u2f(cur_lo.w));
           if (cur_hi.w & F_TRANSLATE) p = vadd(p, off);
           if (cur_hi.w & F_FLIP) n = vneg(n);
-          hp = p, hn = n, hmat = cur_hi.z;
+          hp = p, hn = n, hmat = cur_hi.z | ((cur_hi.w & F_TEXTURED) << 12);
           best = t, tag = depth, nhits++;
         }
         pc += 16u;
@@ -404,7 +417,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         if (rect_hit_t(o, d, axis, u2f(cur_lo.x), u2f(cur_lo.y), u2f(cur_lo.z), u2f(cur_lo.w), u2f(cur_hi.x), t_near, best, t)) {
           V3 n = mk(axis == 0 ? 1.f : 0.f, axis == 1 ? 1.f : 0.f, axis == 2 ? 1.f : 0.f);
           if (cur_hi.w & F_FLIP) n = vneg(n);
-          hp = vadd(o, smul(t, d)), hn = n, hmat = cur_hi.z;
+          hp = vadd(o, smul(t, d)), hn = n, hmat = cur_hi.z | ((cur_hi.w & F_TEXTURED) << 12);
           best = t, tag = depth, nhits++;
         }
         pc += 16u;
@@ -414,7 +427,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         uint32_t face = 0;
         const uint32_t nh = prism_hit_t(cur_lo, cur_hi, o, d, t_near, best, t, face);
         if (nh) {
-          hp = vadd(o, smul(t, d)), hn = prism_normal(face), hmat = cur_hi.z;
+          hp = vadd(o, smul(t, d)), hn = prism_normal(face), hmat = cur_hi.z | ((cur_hi.w & F_TEXTURED) << 12);
           best = t, tag = depth, nhits += nh;
         }
         pc += 16u;
@@ -479,7 +492,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
               float t = t1 + hit_distance / len;
               bool accept = !(cur_hi.w & F_UNDER_BVH) || nhits == root_hits || !(best < t);
               if (accept) {
-                hp = vadd(o, smul(t, d)), hn = mk(1.f, 0.f, 0.f), hmat = cur_hi.z;
+                hp = vadd(o, smul(t, d)), hn = mk(1.f, 0.f, 0.f), hmat = cur_hi.z | ((cur_hi.w & F_TEXTURED) << 12);
                 best = t, tag = depth, nhits++;
               }
             }

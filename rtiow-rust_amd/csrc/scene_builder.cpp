@@ -240,6 +240,13 @@ void push(FlatScene* s, float a, float b, float c, float d, uint32_t e, uint32_t
 }
 }  // namespace
 
+// copies of material facts into a primitive's flag word: MatKind and "reads a non-constant texture"
+static uint32_t mat_flags(const SceneBuilder& b, uint32_t mat) {
+  const HostMaterial& m = b.materials[mat];
+  const bool textured = m.tex != 0xffffffffu && b.textures[m.tex].kind != TEX_CONSTANT;
+  return (m.kind << F_MATKIND_SHIFT) | (textured ? F_TEXTURED : 0u);
+}
+
 // Peel FlipNormals* [Translate] FlipNormals* Sphere, or FlipNormals* Rect, into one fused record.
 // (FlipNormals commutes exactly with Translate: one negates the normal, the other shifts p.)
 static bool fuse_primitive(const SceneBuilder& b, uint32_t id, FlatScene* out, bool emit_it) {
@@ -257,12 +264,12 @@ static bool fuse_primitive(const SceneBuilder& b, uint32_t id, FlatScene* out, b
     } else if (o.kind == HostObject::SPHERE) {
       if (emit_it)
         push(out, off[0], off[1], off[2], o.f[0], 0, 0, o.mat,
-             OP_SPHERE | (have_t ? F_TRANSLATE : 0u) | (flip ? F_FLIP : 0u) | (b.materials[o.mat].kind << F_MATKIND_SHIFT));
+             OP_SPHERE | (have_t ? F_TRANSLATE : 0u) | (flip ? F_FLIP : 0u) | mat_flags(b, o.mat));
       return true;
     } else if (o.kind == HostObject::RECT && !have_t) {
       if (emit_it) {
         push(out, o.f[0], o.f[1], o.f[2], o.f[3], fbits(o.f[4]), 0, o.mat,
-             OP_RECT | ((uint32_t)o.axis << F_AXIS_SHIFT) | (flip ? F_FLIP : 0u) | (b.materials[o.mat].kind << F_MATKIND_SHIFT));
+             OP_RECT | ((uint32_t)o.axis << F_AXIS_SHIFT) | (flip ? F_FLIP : 0u) | mat_flags(b, o.mat));
         out->features |= FEAT_RECT;
       }
       return true;
@@ -324,7 +331,7 @@ void SceneBuilder::emit(uint32_t id, bool under_bvh, bool and_in_bvh, int depth,
       float p0[3], p1[3];
       uint32_t mat;
       if (match_prism(*this, id, p0, p1, &mat)) {
-        push(out, p0[0], p1[0], p0[1], p1[1], fbits(p0[2]), fbits(p1[2]), mat, OP_PRISM | (materials[mat].kind << F_MATKIND_SHIFT));
+        push(out, p0[0], p1[0], p0[1], p1[1], fbits(p0[2]), fbits(p1[2]), mat, OP_PRISM | mat_flags(*this, mat));
         out->features |= FEAT_RECT;
         return;
       }
@@ -347,7 +354,7 @@ void SceneBuilder::emit(uint32_t id, bool under_bvh, bool and_in_bvh, int depth,
         const size_t at = out->lo.size();
         const bool single = fuse_primitive(*this, o.a, out, false);
         push(out, o.f[0], 0, 0, 0, 0, 0, o.mat,
-             OP_MEDIUM | (under_bvh ? F_UNDER_BVH : 0u) | (single ? 0u : F_GENERAL_BOUNDARY) | (materials[o.mat].kind << F_MATKIND_SHIFT));
+             OP_MEDIUM | (under_bvh ? F_UNDER_BVH : 0u) | (single ? 0u : F_GENERAL_BOUNDARY) | mat_flags(*this, o.mat));
         // the boundary's own stream: evaluated twice per medium test by a nested walk (object.rs:551-552),
         // skipped by the main walk.  It starts a fresh wrapper depth (its rays are saved on a private stack).
         if (single) fuse_primitive(*this, o.a, out, true);
