@@ -524,6 +524,12 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
 #if RT_BOX_UNROLL >= 2
         RT_BOX_STEP();  // lanes that left the BOX state sit this one out; the schedule check runs every other step
 #endif
+#if RT_BOX_UNROLL >= 3
+        RT_BOX_STEP();
+#endif
+#if RT_BOX_UNROLL >= 4
+        RT_BOX_STEP();
+#endif
         n_now = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(RT_IS_BOX()));
         if (COUNT) n_box_lanes += n_now;
       } while (n_now > floor_lanes);

@@ -113,6 +113,119 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   uint32_t n_box_it = 0, n_box_lanes = 0, n_slow_it = 0, n_slow_lanes = 0, n_shade = 0, n_shade_lanes = 0, n_refill = 0;
   unsigned long long t_shade = 0, t_serv = 0, t_box = 0, t_slow = 0, t_mark = 0, t_mark2 = 0;  // COUNT: s_memtime shares
 
+  // One non-BOX record for one ray.  The ray's registers are passed explicitly: the traversal lanes run
+  // it on their own ray, the list pass on rays it loads from path slots.
+  auto exec_op = [&](const uint32_t op, V3& o, V3& d, V3& inv, const float time, float& best, uint32_t& pc, const uint4 cur_lo,
+                     const uint4 cur_hi, V3& hp, V3& hn, uint32_t& hmat, uint32_t& depth, uint32_t& tag, uint32_t& nhits,
+                     const uint32_t root_hits, uint32_t& ev_draws, const uint32_t r_pixel, const uint32_t r_sample,
+                     const uint32_t r_event, float* stack) {
+    if (op == OP_SPHERE) {  // Sphere::hit, object.rs:84-111 (+ fused Translate / FlipNormals)
+      if (COUNT) cnt.prim++;
+      const V3 off = mk(u2f(cur_lo.x), u2f(cur_lo.y), u2f(cur_lo.z));
+      V3 lo_o = o;
+      if (cur_hi.w & F_TRANSLATE) lo_o = vsub(o, off);
+      float t;
+      if (sphere_hit_t(lo_o, d, u2f(cur_lo.w), t_near, best, t)) {
+        V3 p = vadd(lo_o, smul(t, d));
+        V3 n = sdiv(p, u2f(cur_lo.w));
+        if (cur_hi.w & F_TRANSLATE) p = vadd(p, off);
+        if (cur_hi.w & F_FLIP) n = vneg(n);
+        hp = p, hn = n, hmat = cur_hi.z | ((cur_hi.w & F_TEXTURED) << 12);
+        best = t, tag = depth, nhits++;
+      }
+      pc += 16u;
+    } else if (op == OP_RECT) {  // Rect::hit, object.rs:185-218
+      if (COUNT) cnt.prim++;
+      const uint32_t axis = (cur_hi.w >> F_AXIS_SHIFT) & 3u;
+      float t;
+      if (rect_hit_t(o, d, axis, u2f(cur_lo.x), u2f(cur_lo.y), u2f(cur_lo.z), u2f(cur_lo.w), u2f(cur_hi.x), t_near, best, t)) {
+        V3 n = mk(axis == 0 ? 1.f : 0.f, axis == 1 ? 1.f : 0.f, axis == 2 ? 1.f : 0.f);
+        if (cur_hi.w & F_FLIP) n = vneg(n);
+        hp = vadd(o, smul(t, d)), hn = n, hmat = cur_hi.z | ((cur_hi.w & F_TEXTURED) << 12);
+        best = t, tag = depth, nhits++;
+      }
+      pc += 16u;
+    } else if (op == OP_PRISM) {  // rect_prism: six Rect::hit in one instruction
+      if (COUNT) cnt.prim += 6;
+      float t;
+      uint32_t face = 0;
+      const uint32_t nh = prism_hit_t(cur_lo, cur_hi, o, d, t_near, best, t, face);
+      if (nh) {
+        hp = vadd(o, smul(t, d)), hn = prism_normal(face), hmat = cur_hi.z | ((cur_hi.w & F_TEXTURED) << 12);
+        best = t, tag = depth, nhits += nh;
+      }
+      pc += 16u;
+    } else if (op == OP_PUSH) {
+      const uint32_t kind = (cur_hi.w >> F_KIND_SHIFT) & 7u;
+      float* sp = stack + depth * (6u * 64u) + lane;
+      sp[0] = o.x, sp[64] = o.y, sp[128] = o.z, sp[192] = d.x, sp[256] = d.y, sp[320] = d.z;
+      depth++;
+      const V3 a = mk(u2f(cur_lo.x), u2f(cur_lo.y), u2f(cur_lo.z));
+      if (cur_hi.w & F_PRE_TRANSLATE) o = vsub(o, mk(u2f(cur_lo.w), u2f(cur_hi.x), u2f(cur_hi.y)));
+      if (kind == XF_TRANSLATE) {
+        o = vsub(o, a);
+      } else if (kind == XF_ROTATE_Y) {
+        o = rot_y(o, -a.x, a.y), d = rot_y(d, -a.x, a.y);
+        inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+      } else if (kind == XF_SCALE) {
+        o = vdiv(o, a), d = vdiv(d, a);
+        inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+      } else if (kind == XF_MOVE) {
+        o = vsub(o, smul(time, a));
+      }
+      pc += 16u;
+    } else if (op == OP_POP) {
+      const uint32_t kind = (cur_hi.w >> F_KIND_SHIFT) & 7u;
+      depth--;
+      if (hmat != NO_HIT && tag == depth + 1u) {
+        const V3 a = mk(u2f(cur_lo.x), u2f(cur_lo.y), u2f(cur_lo.z));
+        if (kind == XF_TRANSLATE) {
+          hp = vadd(hp, a);
+        } else if (kind == XF_ROTATE_Y) {
+          hp = rot_y(hp, a.x, a.y), hn = rot_y(hn, a.x, a.y);
+        } else if (kind == XF_SCALE) {
+          hp = vmul(hp, a), hn = vdiv(hn, a);
+        } else if (kind == XF_FLIP) {
+          hn = vneg(hn);
+        }
+        if (cur_hi.w & F_PRE_TRANSLATE) hp = vadd(hp, mk(u2f(cur_lo.w), u2f(cur_hi.x), u2f(cur_hi.y)));
+        tag = depth;
+      }
+      const float* sp = stack + depth * (6u * 64u) + lane;
+      o = mk(sp[0], sp[64], sp[128]), d = mk(sp[192], sp[256], sp[320]);
+      if (kind == XF_ROTATE_Y || kind == XF_SCALE) inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+      pc += 16u;
+    } else if (op == OP_MEDIUM) {  // ConstantMedium::hit, object.rs:545-575
+      // (scenes whose medium boundary is an object graph -- F_GENERAL_BOUNDARY -- are routed to the
+      // baseline kernel by the host: the nested boundary walk would cost every scene ~20 VGPRs here)
+      const uint4 blo = RT_FETCH_LO(pc + 16u), bhi = RT_FETCH_HI(pc + 16u);
+      float t1, t2;
+      uint32_t n_tests;
+      const bool crossed = boundary_pair_t(blo, bhi, o, d, t1, t2, n_tests);
+      if (COUNT) cnt.prim += n_tests;
+      if (crossed) {
+        t1 = rs_max(t1, t_near);
+        t2 = rs_min(t2, best);
+        if (!(t1 >= t2)) {
+          const float len = vlen(d);
+          float distance_inside = (t2 - t1) * len;
+          float hit_distance = -(1.f / u2f(cur_lo.x)) * rt_logf(event_draw_f32(seed, r_pixel, r_sample, r_event, ev_draws));
+          ev_draws++;
+          if (COUNT) total_draws++;
+          if (hit_distance < distance_inside) {
+            float t = t1 + hit_distance / len;
+            bool accept = !(cur_hi.w & F_UNDER_BVH) || nhits == root_hits || !(best < t);
+            if (accept) {
+              hp = vadd(o, smul(t, d)), hn = mk(1.f, 0.f, 0.f), hmat = cur_hi.z | ((cur_hi.w & F_TEXTURED) << 12);
+              best = t, tag = depth, nhits++;
+            }
+          }
+        }
+      }
+      pc = cur_hi.x;  // first record after the boundary's stream
+    }
+  };
+
   for (;;) {
     uint32_t op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
     const uint64_t m_box = __builtin_amdgcn_ballot_w64(op == OP_BOX);
@@ -395,111 +508,8 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
 #pragma unroll 1
       for (uint32_t ahead = 0;; ahead++) {
       if (COUNT) n_slow_it++, n_slow_lanes += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op >= OP_SPHERE && op <= OP_PRISM));
-      if (op == OP_SPHERE) {  // Sphere::hit, object.rs:84-111 (+ fused Translate / FlipNormals)
-        if (COUNT) cnt.prim++;
-        const V3 off = mk(u2f(cur_lo.x), u2f(cur_lo.y), u2f(cur_lo.z));
-        V3 lo_o = o;
-        if (cur_hi.w & F_TRANSLATE) lo_o = vsub(o, off);
-        float t;
-        if (sphere_hit_t(lo_o, d, u2f(cur_lo.w), t_near, best, t)) {
-          V3 p = vadd(lo_o, smul(t, d));
-          V3 n = sdiv(p, u2f(cur_lo.w));
-          if (cur_hi.w & F_TRANSLATE) p = vadd(p, off);
-          if (cur_hi.w & F_FLIP) n = vneg(n);
-          hp = p, hn = n, hmat = cur_hi.z | ((cur_hi.w & F_TEXTURED) << 12);
-          best = t, tag = depth, nhits++;
-        }
-        pc += 16u;
-      } else if (op == OP_RECT) {  // Rect::hit, object.rs:185-218
-        if (COUNT) cnt.prim++;
-        const uint32_t axis = (cur_hi.w >> F_AXIS_SHIFT) & 3u;
-        float t;
-        if (rect_hit_t(o, d, axis, u2f(cur_lo.x), u2f(cur_lo.y), u2f(cur_lo.z), u2f(cur_lo.w), u2f(cur_hi.x), t_near, best, t)) {
-          V3 n = mk(axis == 0 ? 1.f : 0.f, axis == 1 ? 1.f : 0.f, axis == 2 ? 1.f : 0.f);
-          if (cur_hi.w & F_FLIP) n = vneg(n);
-          hp = vadd(o, smul(t, d)), hn = n, hmat = cur_hi.z | ((cur_hi.w & F_TEXTURED) << 12);
-          best = t, tag = depth, nhits++;
-        }
-        pc += 16u;
-      } else if (op == OP_PRISM) {  // rect_prism: six Rect::hit in one instruction
-        if (COUNT) cnt.prim += 6;
-        float t;
-        uint32_t face = 0;
-        const uint32_t nh = prism_hit_t(cur_lo, cur_hi, o, d, t_near, best, t, face);
-        if (nh) {
-          hp = vadd(o, smul(t, d)), hn = prism_normal(face), hmat = cur_hi.z | ((cur_hi.w & F_TEXTURED) << 12);
-          best = t, tag = depth, nhits += nh;
-        }
-        pc += 16u;
-      } else if (op == OP_PUSH) {
-        const uint32_t kind = (cur_hi.w >> F_KIND_SHIFT) & 7u;
-        float* sp = stack + depth * (6u * 64u) + lane;
-        sp[0] = o.x, sp[64] = o.y, sp[128] = o.z, sp[192] = d.x, sp[256] = d.y, sp[320] = d.z;
-        depth++;
-        const V3 a = mk(u2f(cur_lo.x), u2f(cur_lo.y), u2f(cur_lo.z));
-        if (cur_hi.w & F_PRE_TRANSLATE) o = vsub(o, mk(u2f(cur_lo.w), u2f(cur_hi.x), u2f(cur_hi.y)));
-        if (kind == XF_TRANSLATE) {
-          o = vsub(o, a);
-        } else if (kind == XF_ROTATE_Y) {
-          o = rot_y(o, -a.x, a.y), d = rot_y(d, -a.x, a.y);
-          inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
-        } else if (kind == XF_SCALE) {
-          o = vdiv(o, a), d = vdiv(d, a);
-          inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
-        } else if (kind == XF_MOVE) {
-          o = vsub(o, smul(time, a));
-        }
-        pc += 16u;
-      } else if (op == OP_POP) {
-        const uint32_t kind = (cur_hi.w >> F_KIND_SHIFT) & 7u;
-        depth--;
-        if (hmat != NO_HIT && tag == depth + 1u) {
-          const V3 a = mk(u2f(cur_lo.x), u2f(cur_lo.y), u2f(cur_lo.z));
-          if (kind == XF_TRANSLATE) {
-            hp = vadd(hp, a);
-          } else if (kind == XF_ROTATE_Y) {
-            hp = rot_y(hp, a.x, a.y), hn = rot_y(hn, a.x, a.y);
-          } else if (kind == XF_SCALE) {
-            hp = vmul(hp, a), hn = vdiv(hn, a);
-          } else if (kind == XF_FLIP) {
-            hn = vneg(hn);
-          }
-          if (cur_hi.w & F_PRE_TRANSLATE) hp = vadd(hp, mk(u2f(cur_lo.w), u2f(cur_hi.x), u2f(cur_hi.y)));
-          tag = depth;
-        }
-        const float* sp = stack + depth * (6u * 64u) + lane;
-        o = mk(sp[0], sp[64], sp[128]), d = mk(sp[192], sp[256], sp[320]);
-        if (kind == XF_ROTATE_Y || kind == XF_SCALE) inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
-        pc += 16u;
-      } else if (op == OP_MEDIUM) {  // ConstantMedium::hit, object.rs:545-575
-        // (scenes whose medium boundary is an object graph -- F_GENERAL_BOUNDARY -- are routed to the
-        // baseline kernel by the host: the nested boundary walk would cost every scene ~20 VGPRs here)
-        const uint4 blo = RT_FETCH_LO(pc + 16u), bhi = RT_FETCH_HI(pc + 16u);
-        float t1, t2;
-        uint32_t n_tests;
-        const bool crossed = boundary_pair_t(blo, bhi, o, d, t1, t2, n_tests);
-        if (COUNT) cnt.prim += n_tests;
-        if (crossed) {
-          t1 = rs_max(t1, t_near);
-          t2 = rs_min(t2, best);
-          if (!(t1 >= t2)) {
-            const float len = vlen(d);
-            float distance_inside = (t2 - t1) * len;
-            float hit_distance = -(1.f / u2f(cur_lo.x)) * rt_logf(event_draw_f32(seed, r_pixel, r_sample, r_event, ev_draws));
-            ev_draws++;
-            if (COUNT) total_draws++;
-            if (hit_distance < distance_inside) {
-              float t = t1 + hit_distance / len;
-              bool accept = !(cur_hi.w & F_UNDER_BVH) || nhits == root_hits || !(best < t);
-              if (accept) {
-                hp = vadd(o, smul(t, d)), hn = mk(1.f, 0.f, 0.f), hmat = cur_hi.z | ((cur_hi.w & F_TEXTURED) << 12);
-                best = t, tag = depth, nhits++;
-              }
-            }
-          }
-        }
-        pc = cur_hi.x;  // first record after the boundary's stream
-      }
+      exec_op(op, o, d, inv, time, best, pc, cur_lo, cur_hi, hp, hn, hmat, depth, tag, nhits, root_hits, ev_draws, r_pixel, r_sample,
+              r_event, stack);
       if (op >= OP_SPHERE && op <= OP_PRISM) {
         cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc), op = cur_hi.w & 0xffu;
         if ((cur_hi.w & F_GATHER) && !release) op = 0xfeu;  // arrived at a gather point: wait for the next batch
