@@ -156,6 +156,8 @@ struct rtg_scene {
   unsigned long long* d_counters = nullptr;  // [0..4] N/P/H/rays/draws, [7] = work-queue head (persistent kernel)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int num_cus = 0;
+  float* d_frame = nullptr;     // rtg_par_cast: device staging frame for host framebuffers
+  size_t frame_bytes = 0;
   float* d_stack = nullptr;     // full-feature pool kernel: per-wave transform stacks
   size_t stack_bytes = 0;
   uint32_t* d_slots = nullptr;  // ray-pool path slots when they live in global memory
@@ -654,6 +656,7 @@ void rtg_scene_destroy(rtg_scene* s) {
   if (s->d_scratch) (void)hipFree(s->d_scratch);
   if (s->d_slots) (void)hipFree(s->d_slots);
   if (s->d_stack) (void)hipFree(s->d_stack);
+  if (s->d_frame) (void)hipFree(s->d_frame);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   delete s;
@@ -830,17 +833,19 @@ int rtg_par_cast(rtg_scene* s, const rtg_camera* camera, const rtg_params* param
   if (!s || !params || !out_rgb) return fail(RTG_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(s->device));
   size_t bytes = (size_t)params->nx * params->ny * 3 * sizeof(float);
-  float* d_out = nullptr;
-  HIP_TRY(hipMalloc((void**)&d_out, bytes ? bytes : 16));
-  // pixels of other ranks stay as the caller left them
-  hipError_t e = hipMemcpy(d_out, out_rgb, bytes, hipMemcpyHostToDevice);
+  // the staging frame lives with the scene handle (no hipMalloc / hipFree per call)
+  hipError_t e = grow((void**)&s->d_frame, &s->frame_bytes, bytes ? bytes : 16);
+  if (e != hipSuccess) return hip_fail(e, "hipMalloc(framebuffer)");
+  float* d_out = s->d_frame;
+  // pixels of other ranks stay as the caller left them; a single rank overwrites every pixel
+  const bool partial = params->nranks > 1;
+  if (partial) e = hipMemcpy(d_out, out_rgb, bytes, hipMemcpyHostToDevice);
   int rc = (e == hipSuccess) ? rtg_par_cast_device(s, camera, params, d_out, nullptr, stats) : hip_fail(e, "hipMemcpy");
   if (rc == RTG_OK) {
     e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(out_rgb, d_out, bytes, hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = hip_fail(e, "render / copy back");
   }
-  (void)hipFree(d_out);
   return rc;
 }
 
