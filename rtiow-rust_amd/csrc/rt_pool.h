@@ -48,7 +48,94 @@ struct ChunkMode {
   uint32_t chunk;      // samples per work item
   uint32_t n_chunks;   // work items per pixel
   uint32_t pix_work;   // pixel work items of this rank (tiles x tile area, incl. out-of-image padding)
+  // Cost-ordered queue ("longest processing time first"), lpt != null.  The end of a frame is a chain
+  // problem, not a throughput problem: a path that runs into the bounce cap (glass: ~0.2 % of book-1's
+  // samples) needs 51 dependent traverse + scatter generations, and the ones that START late finish
+  // ~1.2 ms after the queue is empty (measured: fixed cost per C2 launch 1.69 ms at cap 50, 0.46 ms at
+  // cap 4).  So the first `phase1` chunks run in natural order while every scatter event is counted per
+  // 256-pixel block; during the last of them each reservation files its block under one of 64
+  // logarithmic cost classes; the remaining chunks run block-major, classes in descending cost order:
+  // long-path-prone blocks first, sky last.  Order never changes results (per-event RNG streams,
+  // ordered fold).
+  const struct LptQueue* lpt;
+  uint32_t lpt_samples;  // samples [0, lpt_samples) of every pixel belong to phase 1 (0 = off)
+  uint32_t lpt_deep;     // a scatter event counts towards its block's cost from this bounce on
 };
+constexpr uint32_t LPT_BLOCK = 256;   // pixels per cost block = WORK_BLOCK
+constexpr uint32_t LPT_CLASSES = 64;  // one per lane
+constexpr uint32_t LPT_CTL = 80;      // count[64], [64] = blocks filed so far
+struct LptQueue {       // lives in device memory: the kernels touch it once per 256-item reservation
+  uint32_t* cost;       // [n_blocks] scatter events per block during phase 1
+  uint32_t* ctl;        // [LPT_CTL]
+  uint32_t* list;       // [LPT_CLASSES][n_blocks] blocks of each class, in filing order
+  uint32_t n_blocks;
+  uint32_t phase1;      // chunks in natural order
+  uint32_t phase2_base; // first phase-2 work item = phase1 * pix_work
+  uint32_t span;        // phase-2 items per block = LPT_BLOCK * (n_chunks - phase1)
+  uint32_t mode;        // 1: block-major (all chunks of a block back to back); 2: per class, chunk-major
+  uint32_t shift;       // classes are merged in groups of 1 << shift
+};
+
+RT_DEV uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// phase 1: lanes with `on` add one to their block's cost -- one atomic per distinct block of the wave
+// (a pass mostly holds samples of one or two blocks; 64 same-address atomics cost Cornell 25 %)
+RT_DEV void lpt_count(const ChunkMode& cm, bool on, uint32_t blk) {
+  uint64_t todo = __builtin_amdgcn_ballot_w64(on);
+  while (todo) {
+    const uint32_t b0 = __builtin_amdgcn_readlane(blk, (uint32_t)__builtin_ctzll(todo));
+    const uint64_t same = __builtin_amdgcn_ballot_w64(on && blk == b0);
+    if (on && blk == b0 && lane_rank(same) == 0u) atomicAdd(&cm.lpt->cost[b0], (uint32_t)__builtin_popcountll(same));
+    todo &= ~same;
+  }
+}
+
+// A wave reserved work items [base, base + WORK_BLOCK): they all belong to one chunk and one 256-pixel
+// block (pix_work is a multiple of 256).  Returns the chunk; item w is pixel work index w + delta.
+RT_DEV uint32_t lpt_reservation(const ChunkMode& cm, uint32_t base, uint32_t lane, uint32_t& delta, bool& ready) {
+  const LptQueue* q = cm.lpt;
+  if (q == nullptr || base < q->phase2_base) {
+    const uint32_t c = base / cm.pix_work;
+    delta = 0u - c * cm.pix_work;
+    if (q != nullptr && c + 1u == q->phase1) {  // last natural-order chunk: file this block under its cost class
+      const uint32_t blk = (base + delta) >> 8;
+      if (lane == 0u) {
+        const uint32_t v = ld_agent(q->cost + blk) + 1u;            // class = 4 per octave of (cost + 1), 0 = most expensive
+        const uint32_t e = 31u - (uint32_t)__builtin_clz(v);
+        const uint32_t k = 4u * e + (e >= 2u ? ((v >> (e - 2u)) & 3u) : ((v << (2u - e)) & 3u));
+        const uint32_t cls = (LPT_CLASSES - 1u - (k > LPT_CLASSES - 1u ? LPT_CLASSES - 1u : k)) >> q->shift;
+        const uint32_t pos = atomicAdd(&q->ctl[cls], 1u);
+        __hip_atomic_store(q->list + (size_t)cls * q->n_blocks + pos, blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&q->ctl[LPT_CLASSES], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    return c;
+  }
+  const uint32_t n = q->n_blocks;
+  if (!ready) {  // once per wave: an agent-scope acquire drops the CU's L1, which the path slots live in
+    while (__hip_atomic_load(&q->ctl[LPT_CLASSES], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < n) __builtin_amdgcn_s_sleep(8);
+    ready = true;
+  }
+  const uint32_t span = q->span, w2 = base - q->phase2_base;
+  const uint32_t r = w2 / span, rem = w2 - r * span;  // r-th block of the class order, chunk phase1 + rem / 256
+  const uint32_t cnt = q->ctl[lane];  // ctl[] and list[] no longer change: ordinary cached loads
+  uint32_t incl = cnt;
+  for (int k = 1; k < 64; k <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_up((int)incl, k, 64);
+    if ((int)lane >= k) incl += t;
+  }
+  const uint32_t cls = (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(incl > r));
+  const uint32_t before = __builtin_amdgcn_readlane(incl - cnt, cls);
+  uint32_t idx = r - before, c = rem >> 8;
+  if (q->mode == 2u) {  // inside the class: chunk-major, blocks in filing order
+    const uint32_t per_chunk = __builtin_amdgcn_readlane(cnt, cls) * LPT_BLOCK, rem_c = w2 - before * span;
+    c = rem_c / per_chunk;
+    idx = (rem_c - c * per_chunk) >> 8;
+  }
+  const uint32_t blk = q->list[(size_t)cls * n + idx];
+  delta = blk * LPT_BLOCK - base;  // reservations are block-aligned
+  return q->phase1 + c;
+}
 
 // inverse of work_to_pixel
 RT_DEV uint32_t pixel_to_work(const DevParams& P, uint32_t x, uint32_t row) {
@@ -191,6 +278,8 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
   const float t_near = P.t_near;
   uint32_t t_count = 0, s_count = 0, e_count = POOL, n_dead = 0;  // wave-uniform list sizes / retired slots
   uint32_t w_next = 0, w_end = 0;                                  // this wave's reserved range of work items
+  uint32_t w_chunk = 0, w_delta = 0;                               // ... their chunk, and pixel work index - item index
+  bool w_lpt_ready = false;
   bool exhausted = false;                                          // the global counter ran past total_work
   const unsigned long long t_start = RT_TICK();
   unsigned long long t_exhausted = 0;
@@ -272,8 +361,8 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
         const uint32_t take = s_count < 64u ? s_count : 64u;
         s_count -= take;
         if (COUNT) n_shade++, n_shade_lanes += take, t_mark2 = RT_TICK();
-        bool live = false, ended = false;
-        uint32_t j = 0;
+        bool live = false, ended = false, lpt_on = false;
+        uint32_t j = 0, lpt_blk = 0;
         if (lane < take) {
           j = slist[s_count + lane];
           const uint32_t bpc = SLOT_U(PF_BEST_PC, j);
@@ -342,6 +431,8 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
             nd = rs;
           }
           if (COUNT) total_draws += rng.draws;
+          lpt_on = s < cm.lpt_samples && bounces == cm.lpt_deep;  // phase 1 of the cost-ordered queue: a deep scatter event
+          if (lpt_on) lpt_blk = pixel_to_work(P, xy & 0xffffu, xy >> 16) >> 8;
           if (scattered) {
             strength = vmul(strength, att);  // lib.rs:87
             if (bounces != P.max_bounces) {  // lib.rs:93-97
@@ -361,6 +452,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           }
           SLOT_F(PF_ACCUM, j) = accum.x, SLOT_F(PF_ACCUM + 1, j) = accum.y, SLOT_F(PF_ACCUM + 2, j) = accum.z;
         }
+        if (cm.lpt_samples) lpt_count(cm, lpt_on, lpt_blk);
         const uint64_t m_live = __builtin_amdgcn_ballot_w64(live), m_ended = __builtin_amdgcn_ballot_w64(ended);
         if (live) tlist[t_count + lane_rank(m_live)] = (uint16_t)j;
         if (ended) elist[e_count + lane_rank(m_ended)] = (uint16_t)j;
@@ -431,6 +523,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
               exhausted = true;
               if (COUNT) t_exhausted = RT_TICK();
             } else {
+              if (cm.scratch) w_chunk = lpt_reservation(cm, base, lane, w_delta, w_lpt_ready);
               w_next = base;
               w_end = (total_work - base < WORK_BLOCK) ? total_work : base + WORK_BLOCK;
             }
@@ -441,9 +534,8 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
             if (r < avail) {
               uint32_t w = w_next + r, first = 0;
               if (cm.scratch) {  // work item = (chunk, pixel), pixel-minor so a wave's grab stays coherent
-                const uint32_t c = w / cm.pix_work;
-                w -= c * cm.pix_work;
-                first = c * cm.chunk;
+                w += w_delta;
+                first = w_chunk * cm.chunk;
               }
               if (work_to_pixel(P, w, x, row) && first < P.ns) {
                 s = first;

@@ -94,7 +94,8 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   const uint64_t seed = ((uint64_t)P.seed_hi << 32) | P.seed_lo;
   const float t_near = P.t_near;
   uint32_t t_count = 0, s_count = POOL, x_count = 0, n_dead = 0;
-  uint32_t w_next = 0, w_end = 0;
+  uint32_t w_next = 0, w_end = 0, w_chunk = 0, w_delta = 0;
+  bool w_lpt_ready = false;
   bool exhausted = false;
 
   // ---- per-lane traversal state ---------------------------------------------------------------
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         V3 so = mk(0.f, 0.f, 0.f), sd = so, strength = so, accum = so;
         float stime = 0.f;
         uint32_t bounces = 0, s = 0, x = 0, row = 0;
+        bool lpt_on = false;
         if (lane < take) {
           j = list[count + lane];
           const uint32_t hm = SLOT_U(FF_HITMAT, j);
@@ -351,6 +353,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
                 if (bounces != P.max_bounces) {
                   bounces += 1;
                   ended = false;
+                  lpt_on = s < cm.lpt_samples && bounces == cm.lpt_deep;  // phase 1 of the cost-ordered queue (rt_pool.h)
                 }
               }
             }
@@ -365,6 +368,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
             }
           }
         }
+        if (cm.lpt_samples) lpt_count(cm, lpt_on, lpt_on ? pixel_to_work(P, x, row) >> 8 : 0u);
         for (;;) {  // next work item (see rt_pool.h)
           const uint64_t need = __builtin_amdgcn_ballot_w64(st == ST_NEED_PIXEL);
           if (need == 0) break;
@@ -375,6 +379,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
             if (base >= total_work) {
               exhausted = true;
             } else {
+              w_chunk = lpt_reservation(cm, base, lane, w_delta, w_lpt_ready);
               w_next = base;
               w_end = (total_work - base < WORK_BLOCK) ? total_work : base + WORK_BLOCK;
             }
@@ -384,9 +389,8 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
             const uint32_t r = lane_rank(need);
             if (r < avail) {
               uint32_t w = w_next + r;
-              const uint32_t c = w / cm.pix_work;
-              w -= c * cm.pix_work;
-              const uint32_t first = c * cm.chunk;
+              w += w_delta;
+              const uint32_t first = w_chunk * cm.chunk;
               if (work_to_pixel(P, w, x, row) && first < P.ns) {
                 s = first;
                 st = ST_GEN;

@@ -165,6 +165,13 @@ struct rtg_scene {
   float* d_scratch = nullptr;  // chunk-mode per-sample colours
   size_t scratch_bytes = 0;
   int force_chunks = 0;        // RTG_CHUNKS: 0 = automatic
+  uint32_t* d_lpt = nullptr;   // cost-ordered work queue (rt_pool.h LptQueue)
+  size_t lpt_bytes = 0;
+  LptQueue lpt_desc{};         // what the descriptor slot of d_lpt holds
+  int lpt = 2;                 // RTG_LPT=0: natural order throughout; 1 / 2 = LptQueue::mode
+  int lpt_deep = 6;            // RTG_LPT_DEEP: scatter events at bounce >= this make up a block's cost
+  int lpt_shift = 0;           // RTG_LPT_SHIFT: merge cost classes in groups of 1 << shift
+  int lpt_phase1 = 0;          // RTG_LPT_PHASE1: chunks in natural order, 0 = n_chunks / 8 clamped to [2, 8]
   // lean scenes: 3 = ray-pool kernel (rt_pool.h), 2 = persistent single-wave regeneration (rt_persistent.h),
   // 1 = one-lane-per-pixel baseline (rt_trace.h).  Non-lean scenes always use 1.
   int kernel_version = 3;
@@ -183,6 +190,7 @@ static uint64_t scratch_cap() {
 }
 
 static uint64_t owned_pixels(const DevParams& d);
+static hipError_t setup_lpt(rtg_scene* s, ChunkMode& cm, uint64_t capacity, hipStream_t stream);
 
 // Lean scenes: persistent wavefronts pulling pixels from a work counter (rt_persistent.h).
 template <bool COUNT>
@@ -271,6 +279,8 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
   // a wave keeps POOL paths in flight; do not launch more waves than there is work for
   uint64_t want = (total_work + (uint64_t)waves * POOL - 1) / ((uint64_t)waves * POOL);
   uint32_t grid = (uint32_t)std::min<uint64_t>(want ? want : 1, (uint64_t)s->num_cus * per_cu);
+  e = setup_lpt(s, cm, (uint64_t)grid * waves * POOL, stream);
+  if (e != hipSuccess) return e;
   if (getenv("RTG_VERBOSE"))
     fprintf(stderr, "[rtg] pool: grid %u x %d threads, %d WG/CU, lds %zu B (program staged: %d), %u chunk(s) of %u samples\n", grid,
             bt, per_cu, lds, (int)use_lds, cm.n_chunks, cm.chunk);
@@ -302,6 +312,43 @@ static hipError_t grow(void** buf, size_t* have, size_t need) {
   hipError_t e = hipMalloc(buf, need);
   if (e == hipSuccess) *have = need;
   return e;
+}
+
+// Cost-ordered work queue (rt_pool.h, ChunkMode): enabled when the frame has enough chunks for a measuring
+// phase and enough blocks to order; the buffers are re-zeroed on the launch stream every call.
+static hipError_t setup_lpt(rtg_scene* s, ChunkMode& cm, uint64_t capacity, hipStream_t stream) {
+  cm.lpt = nullptr, cm.lpt_samples = 0, cm.lpt_deep = 0;
+  const uint32_t n_blocks = cm.pix_work / LPT_BLOCK;
+  if (!s->lpt || !cm.scratch || cm.n_chunks < 6 || n_blocks < 64 || n_blocks > 65536 || cm.pix_work % LPT_BLOCK) return hipSuccess;
+  // Phase 1 must outlast the first fill of the pools (`capacity` paths in flight) by enough for the
+  // counts to mean something when the blocks are filed; it may take up to a third of the frame.
+  uint32_t phase1 = std::max<uint32_t>(std::min(8u, std::max(2u, cm.n_chunks / 8u)), (uint32_t)((2 * capacity + cm.pix_work - 1) / cm.pix_work));
+  if (s->lpt_phase1 > 0) phase1 = (uint32_t)s->lpt_phase1;
+  if (phase1 < 1 || phase1 > cm.n_chunks / 3) return hipSuccess;
+  // layout: [descriptor, 64 B] [cost n] [ctl LPT_CTL] [list LPT_CLASSES x n]
+  const size_t words = 16 + (size_t)n_blocks * (1 + LPT_CLASSES) + LPT_CTL;
+  if (words * sizeof(uint32_t) > s->lpt_bytes) memset(&s->lpt_desc, 0, sizeof(s->lpt_desc));
+  hipError_t e = grow((void**)&s->d_lpt, &s->lpt_bytes, words * sizeof(uint32_t));
+  if (e != hipSuccess) return e;
+  LptQueue q;
+  memset(&q, 0, sizeof(q));
+  static_assert(sizeof(LptQueue) <= 64, "descriptor slot");
+  q.cost = s->d_lpt + 16, q.ctl = q.cost + n_blocks, q.list = q.ctl + LPT_CTL;
+  q.n_blocks = n_blocks, q.phase1 = phase1;
+  q.phase2_base = phase1 * cm.pix_work;
+  q.span = LPT_BLOCK * (cm.n_chunks - phase1);
+  q.mode = (uint32_t)s->lpt, q.shift = (uint32_t)s->lpt_shift;
+  if (memcmp(&q, &s->lpt_desc, sizeof(q)) != 0) {  // the descriptor only changes with the frame geometry
+    e = hipMemcpy(s->d_lpt, &q, sizeof(q), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return e;
+    s->lpt_desc = q;
+  }
+  e = hipMemsetAsync(q.cost, 0, ((size_t)n_blocks + LPT_CTL) * sizeof(uint32_t), stream);
+  if (e != hipSuccess) return e;
+  cm.lpt = reinterpret_cast<const LptQueue*>(s->d_lpt);
+  cm.lpt_samples = phase1 * cm.chunk;
+  cm.lpt_deep = (uint32_t)s->lpt_deep;
+  return hipSuccess;
 }
 
 // Full-feature scenes, ray-pool kernel (rt_pool_full.h).  Returns hipErrorNotSupported when the sample
@@ -355,6 +402,8 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
   if (per_cu < 1) per_cu = 1;
   uint64_t want = (total_work + (uint64_t)waves * POOL - 1) / ((uint64_t)waves * POOL);
   uint32_t grid = (uint32_t)std::min<uint64_t>(want ? want : 1, (uint64_t)s->num_cus * per_cu);
+  e = setup_lpt(s, cm, (uint64_t)grid * waves * POOL, stream);
+  if (e != hipSuccess) return e;
   e = grow((void**)&s->d_slots, &s->slots_bytes, (size_t)grid * waves * POOL * FPOOL_FIELDS * sizeof(uint32_t));
   if (e != hipSuccess) return e;
   e = grow((void**)&s->d_stack, &s->stack_bytes, (size_t)grid * waves * MAX_XFORM_DEPTH * 6 * 64 * sizeof(float));
@@ -656,6 +705,7 @@ void rtg_scene_destroy(rtg_scene* s) {
   if (s->d_scratch) (void)hipFree(s->d_scratch);
   if (s->d_slots) (void)hipFree(s->d_slots);
   if (s->d_stack) (void)hipFree(s->d_stack);
+  if (s->d_lpt) (void)hipFree(s->d_lpt);
   if (s->d_frame) (void)hipFree(s->d_frame);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -704,6 +754,10 @@ int rtg_scene_create(rtg_builder* b, const rtg_id* world, size_t n, int device, 
   if (s->num_cus <= 0) s->num_cus = 256;
   if (const char* kv = getenv("RTG_KERNEL")) s->kernel_version = atoi(kv);  // A/B switches for measurements
   if (const char* kv = getenv("RTG_CHUNKS")) s->force_chunks = atoi(kv);
+  if (const char* kv = getenv("RTG_LPT")) s->lpt = atoi(kv);
+  if (const char* kv = getenv("RTG_LPT_PHASE1")) s->lpt_phase1 = atoi(kv);
+  if (const char* kv = getenv("RTG_LPT_DEEP")) s->lpt_deep = atoi(kv);
+  if (const char* kv = getenv("RTG_LPT_SHIFT")) s->lpt_shift = std::min(6, std::max(0, atoi(kv)));
   if (const char* kv = getenv("RTG_BLOCK")) s->block_threads = s->pool_threads = s->full_threads = atoi(kv);
   if (const char* kv = getenv("RTG_WG_PER_CU")) s->wg_per_cu = atoi(kv);
   if (const char* kv = getenv("RTG_REGEN_MIN")) s->tune.regen_min = (uint32_t)atoi(kv);
