@@ -79,5 +79,6 @@ constexpr uint32_t FEAT_MEDIUM = 2u;   // MEDIUM present
 constexpr uint32_t FEAT_RECT = 4u;     // RECT present
 constexpr uint32_t FEAT_TEXTURE = 8u;  // a non-constant texture is referenced
 constexpr uint32_t FEAT_BOUNDARY = 16u; // a ConstantMedium whose boundary is an object graph (nested boundary walk)
+constexpr uint32_t FEAT_WIDE_ALBEDO = 32u;  // an albedo component outside [0, 1]: path strength is not bounded by 1 (rt_pool.h PoolField)
 
 }  // namespace rtg

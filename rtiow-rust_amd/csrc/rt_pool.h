@@ -29,15 +29,19 @@ namespace rtg {
 #define RT_POOL_SLOTS 192  // 160-192 measured best on C2; 256+ costs 20-40 % (slot working set vs L2, longer tail)
 #endif
 constexpr uint32_t POOL = RT_POOL_SLOTS;           // path slots per wave: 64 in lanes + 128 waiting, so one wait list always holds >= 64
-constexpr uint32_t POOL_FIELDS = 20;     // dwords per slot (SoA: field f of slot j at [f * POOL + j])
+constexpr uint32_t POOL_FIELDS = 17;     // dwords per slot (SoA: field f of slot j at [f * POOL + j]); 14 in chunk mode
 constexpr uint32_t WORK_BLOCK = 256;     // work items a wave reserves per global atomic (2048 cost 20 % on C2: ~6 blocks per wave = a coarse tail)
 constexpr uint32_t SLOT_NEED_PIXEL = 0xfffffffeu;  // best_pc marker: slot holds no ray yet
 constexpr uint32_t SLOT_ENDED = 0xfffffffdu;       // best_pc marker: path ended in a SCATTER pass, colour parked in accum
 
 enum PoolField : uint32_t {
-  PF_O = 0, PF_D = 3, PF_BEST = 6, PF_BEST_PC = 7, PF_STRENGTH = 8, PF_ACCUM = 11, PF_BOUNCES = 14, PF_SAMPLE = 15,
-  PF_XY = 16, PF_COL = 17,
+  PF_O = 0, PF_D = 3, PF_BEST = 6, PF_BEST_PC = 7, PF_STRENGTH = 8, PF_BOUNCES = 11, PF_SAMPLE = 12, PF_XY = 13, PF_COL = 14,
 };
+// There is no accum field.  color()'s `accum = accum + strength * emitted` (lib.rs:76) adds
+// strength * 0 at every hit on a scattering material (material.rs:126), and a lean scene has no other
+// emitter than the DiffuseLight that ends the path: with every albedo component in [0, 1] (the
+// flattener routes anything else to the full-feature kernel, FEAT_WIDE_ALBEDO) strength stays in
+// [0, 1], strength * 0 = +0 and accum is +0 whenever it is read.  Six fewer slot rows per pass.
 
 // Sample-chunk mode.  One lane per pixel cannot fill the chip when a rank owns few pixels (8-GPU
 // shards, small images).  A work item is then (pixel, chunk of `chunk` consecutive samples); every
@@ -369,7 +373,6 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           V3 so = mk(SLOT_F(PF_O, j), SLOT_F(PF_O + 1, j), SLOT_F(PF_O + 2, j));
           V3 sd = mk(SLOT_F(PF_D, j), SLOT_F(PF_D + 1, j), SLOT_F(PF_D + 2, j));
           V3 strength = mk(SLOT_F(PF_STRENGTH, j), SLOT_F(PF_STRENGTH + 1, j), SLOT_F(PF_STRENGTH + 2, j));
-          V3 accum = mk(SLOT_F(PF_ACCUM, j), SLOT_F(PF_ACCUM + 1, j), SLOT_F(PF_ACCUM + 2, j));
           uint32_t bounces = SLOT_U(PF_BOUNCES, j);
           const uint32_t s = SLOT_U(PF_SAMPLE, j), xy = SLOT_U(PF_XY, j);
           const float hb = SLOT_F(PF_BEST, j);
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           const uint32_t kind = mhi.w & 0xffu;
           const float param = u2f(mlo.w);
           const V3 mcol = mk(u2f(mlo.x), u2f(mlo.y), u2f(mlo.z));
-          accum = vadd(accum, vmul(strength, mk(0.f, 0.f, 0.f)));  // lib.rs:76 with emitted = 0 (material.rs:126)
+          // lib.rs:76 with emitted = 0 (material.rs:126): accum stays +0, see PoolField
           V3 nd = mk(0.f, 0.f, 0.f), att = mcol;
           bool scattered = true;
           // Lambertian, Metal and Isotropic each draw exactly one in_unit_sphere before any other draw of
@@ -450,7 +453,6 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
             ended = true;
             SLOT_U(PF_BEST_PC, j) = SLOT_ENDED;
           }
-          SLOT_F(PF_ACCUM, j) = accum.x, SLOT_F(PF_ACCUM + 1, j) = accum.y, SLOT_F(PF_ACCUM + 2, j) = accum.z;
         }
         if (cm.lpt_samples) lpt_count(cm, lpt_on, lpt_blk);
         const uint64_t m_live = __builtin_amdgcn_ballot_w64(live), m_ended = __builtin_amdgcn_ballot_w64(ended);
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
             x = xy & 0xffffu, row = xy >> 16;
             V3 result = mk(0.f, 0.f, 0.f);  // lib.rs:100: a miss is black, accum is discarded
             if (bpc != NO_HIT) {
-              const V3 accum = mk(SLOT_F(PF_ACCUM, j), SLOT_F(PF_ACCUM + 1, j), SLOT_F(PF_ACCUM + 2, j));
+              const V3 accum = mk(0.f, 0.f, 0.f);
               result = accum;  // SLOT_ENDED: color() already returned accum
               if (bpc != SLOT_ENDED) {  // DiffuseLight hit: lib.rs:76 then scatter() == None (material.rs:108)
                 if (COUNT) cnt.shaded++;
@@ -563,7 +565,6 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           SLOT_F(PF_O, j) = so.x, SLOT_F(PF_O + 1, j) = so.y, SLOT_F(PF_O + 2, j) = so.z;
           SLOT_F(PF_D, j) = sd.x, SLOT_F(PF_D + 1, j) = sd.y, SLOT_F(PF_D + 2, j) = sd.z;
           SLOT_F(PF_STRENGTH, j) = 1.f, SLOT_F(PF_STRENGTH + 1, j) = 1.f, SLOT_F(PF_STRENGTH + 2, j) = 1.f;
-          SLOT_F(PF_ACCUM, j) = 0.f, SLOT_F(PF_ACCUM + 1, j) = 0.f, SLOT_F(PF_ACCUM + 2, j) = 0.f;
           if (!cm.scratch) SLOT_F(PF_COL, j) = col.x, SLOT_F(PF_COL + 1, j) = col.y, SLOT_F(PF_COL + 2, j) = col.z;
           SLOT_U(PF_BOUNCES, j) = 0u, SLOT_U(PF_SAMPLE, j) = s;
           SLOT_U(PF_XY, j) = x | (row << 16);
