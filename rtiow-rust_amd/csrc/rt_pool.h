@@ -26,7 +26,7 @@
 namespace rtg {
 
 #ifndef RT_POOL_SLOTS
-#define RT_POOL_SLOTS 192  // 160-192 measured best on C2; 256+ costs 20-40 % (slot working set vs L2, longer tail)
+#define RT_POOL_SLOTS 144  // 8 global dwords x 144 slots x 4 096 waves = 2.4 MB per XCD: the slot rows stay in the 4 MB L2s
 #endif
 constexpr uint32_t POOL = RT_POOL_SLOTS;           // path slots per wave: 64 in lanes + 128 waiting, so one wait list always holds >= 64
 constexpr uint32_t POOL_FIELDS = 17;     // dwords per slot (SoA: field f of slot j at [f * POOL + j]); 14 in chunk mode
@@ -141,6 +141,19 @@ RT_DEV uint32_t lpt_reservation(const ChunkMode& cm, uint32_t base, uint32_t lan
   return q->phase1 + c;
 }
 
+// The per-sample colours are written once and read once by the fold kernel, 0.58 GB per C2 frame: stream them
+// past the L2, which the path slots want to themselves.
+#ifndef RT_NT_SCRATCH
+#define RT_NT_SCRATCH 1
+#endif
+#if RT_NT_SCRATCH
+#define RT_SCRATCH_STORE(p_, v_) (__builtin_nontemporal_store((v_).x, (p_)), __builtin_nontemporal_store((v_).y, (p_) + 1), __builtin_nontemporal_store((v_).z, (p_) + 2))
+#define RT_SCRATCH_LOAD(p_) __builtin_nontemporal_load(p_)
+#else
+#define RT_SCRATCH_STORE(p_, v_) ((p_)[0] = (v_).x, (p_)[1] = (v_).y, (p_)[2] = (v_).z)
+#define RT_SCRATCH_LOAD(p_) (*(p_))
+#endif
+
 // inverse of work_to_pixel
 RT_DEV uint32_t pixel_to_work(const DevParams& P, uint32_t x, uint32_t row) {
   const uint32_t tiles_x = (P.nx + P.tile_w - 1u) / P.tile_w;
@@ -160,7 +173,7 @@ __global__ void fold_samples_kernel(DevParams P, ChunkMode cm, float* __restrict
   V3 col = mk(0.f, 0.f, 0.f);
   for (uint32_t s = 0; s < P.ns; s++) {
     const float* c = cm.scratch + 3ull * ((size_t)s * cm.pix_work + w);
-    col = vadd(col, mk(c[0], c[1], c[2]));
+    col = vadd(col, mk(RT_SCRATCH_LOAD(c), RT_SCRATCH_LOAD(c + 1), RT_SCRATCH_LOAD(c + 2)));
   }
   col = sdiv(col, (float)P.ns);
   float* o = out + 3ull * ((size_t)row * P.nx + x);
@@ -192,10 +205,12 @@ typedef __attribute__((address_space(3))) const char* lds_cptr;
 // dynamic LDS bytes for a workgroup of `waves` waves.  The path slots live in a per-wave SoA region of
 // global memory (L2-resident; a field access of 64 lanes touches at most 4 cache lines), which leaves
 // LDS to the program and lets 16 waves share a CU.
-inline size_t pool_lds_bytes(uint32_t n_prog, uint32_t n_mat, uint32_t waves, bool stage_program) {
+inline size_t pool_lds_bytes(uint32_t n_prog, uint32_t n_mat, uint32_t waves, bool stage_program, bool ray_lds) {
   size_t b = stage_program ? ((size_t)n_prog * LDS_REC + (size_t)n_mat * 32) : 0;
   b += (size_t)waves * POOL * 3 * 2;  // T-, S- and E-list (u16 slot ids)
-  return (b + 15) & ~(size_t)15;
+  b = (b + 15) & ~(size_t)15;
+  if (ray_lds) b += (size_t)waves * POOL * 6 * sizeof(float);  // the slots' rays (o, d)
+  return b;
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -235,7 +250,10 @@ RT_DEV uint4 fetch_hi_global(const DevScene& sc, uint32_t idx) {  // byte-offset
 // Each pass type runs 64 lanes wide over slots of ITS class, so a wave no longer issues the union of
 // the scatter code and the camera code for every batch of finished rays.  The class of a hit is read
 // from the winning SPHERE record (the flattener copies the material kind into its flag word).
-template <bool USE_LDS, bool COUNT>
+// RAY_LDS: the six most-travelled slot fields -- the ray (o, d): written by the SCATTER and END passes,
+// read by the refill and the SCATTER pass -- live in LDS when the program leaves room; the other
+// fields stay in the global SoA region.
+template <bool USE_LDS, bool COUNT, bool RAY_LDS>
 __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void render_lean_pool(
     DevScene sc, DevCamera cam, DevParams P, float* __restrict__ out, uint32_t total_work, uint32_t* __restrict__ queue,
     unsigned long long* counters, PoolTuning tune, ChunkMode cm, uint32_t* __restrict__ g_slots) {
@@ -269,8 +287,11 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
   uint16_t* tlist = reinterpret_cast<uint16_t*>(s_mem + staged) + wave * (3u * POOL);
   uint16_t* slist = tlist + POOL;
   uint16_t* elist = slist + POOL;
+  float* lds_ray = reinterpret_cast<float*>(reinterpret_cast<char*>(s_mem + staged) + (((size_t)n_waves * POOL * 6u + 15u) & ~(size_t)15u)) +
+                   (size_t)wave * (POOL * 6u);
 #define SLOT_U(f_, j_) slot[(f_)*POOL + (j_)]
 #define SLOT_F(f_, j_) slotf[(f_)*POOL + (j_)]
+#define RAY_F(f_, j_) (*(RAY_LDS ? &lds_ray[(f_)*POOL + (j_)] : &slotf[(f_)*POOL + (j_)]))
   // all slots start as "need a work item", all on the E-list
   for (uint32_t j = lane; j < POOL; j += 64u) {
     SLOT_U(PF_BEST_PC, j) = SLOT_NEED_PIXEL;
@@ -370,8 +391,8 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
         if (lane < take) {
           j = slist[s_count + lane];
           const uint32_t bpc = SLOT_U(PF_BEST_PC, j);
-          V3 so = mk(SLOT_F(PF_O, j), SLOT_F(PF_O + 1, j), SLOT_F(PF_O + 2, j));
-          V3 sd = mk(SLOT_F(PF_D, j), SLOT_F(PF_D + 1, j), SLOT_F(PF_D + 2, j));
+          V3 so = mk(RAY_F(PF_O, j), RAY_F(PF_O + 1, j), RAY_F(PF_O + 2, j));
+          V3 sd = mk(RAY_F(PF_D, j), RAY_F(PF_D + 1, j), RAY_F(PF_D + 2, j));
           V3 strength = mk(SLOT_F(PF_STRENGTH, j), SLOT_F(PF_STRENGTH + 1, j), SLOT_F(PF_STRENGTH + 2, j));
           uint32_t bounces = SLOT_U(PF_BOUNCES, j);
           const uint32_t s = SLOT_U(PF_SAMPLE, j), xy = SLOT_U(PF_XY, j);
@@ -444,8 +465,8 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
             }
           }
           if (live) {
-            SLOT_F(PF_O, j) = hp.x, SLOT_F(PF_O + 1, j) = hp.y, SLOT_F(PF_O + 2, j) = hp.z;
-            SLOT_F(PF_D, j) = nd.x, SLOT_F(PF_D + 1, j) = nd.y, SLOT_F(PF_D + 2, j) = nd.z;
+            RAY_F(PF_O, j) = hp.x, RAY_F(PF_O + 1, j) = hp.y, RAY_F(PF_O + 2, j) = hp.z;
+            RAY_F(PF_D, j) = nd.x, RAY_F(PF_D + 1, j) = nd.y, RAY_F(PF_D + 2, j) = nd.z;
             SLOT_F(PF_STRENGTH, j) = strength.x, SLOT_F(PF_STRENGTH + 1, j) = strength.y, SLOT_F(PF_STRENGTH + 2, j) = strength.z;
             SLOT_U(PF_BOUNCES, j) = bounces;
             if (COUNT) cnt.rays++;
@@ -494,7 +515,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
             }
             if (cm.scratch) {  // chunk mode: park the sample colour, folded in order afterwards
               float* sp = cm.scratch + 3ull * ((size_t)s * cm.pix_work + pixel_to_work(P, x, row));
-              sp[0] = result.x, sp[1] = result.y, sp[2] = result.z;
+              RT_SCRATCH_STORE(sp, result);
             } else {
               col = vadd(mk(SLOT_F(PF_COL, j), SLOT_F(PF_COL + 1, j), SLOT_F(PF_COL + 2, j)), result);  // vec3.rs:195-203
             }
@@ -562,8 +583,8 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           float time;
           get_ray(cam, u, v, rng, so, sd, time);
           if (COUNT) total_draws += rng.draws, cnt.rays++;
-          SLOT_F(PF_O, j) = so.x, SLOT_F(PF_O + 1, j) = so.y, SLOT_F(PF_O + 2, j) = so.z;
-          SLOT_F(PF_D, j) = sd.x, SLOT_F(PF_D + 1, j) = sd.y, SLOT_F(PF_D + 2, j) = sd.z;
+          RAY_F(PF_O, j) = so.x, RAY_F(PF_O + 1, j) = so.y, RAY_F(PF_O + 2, j) = so.z;
+          RAY_F(PF_D, j) = sd.x, RAY_F(PF_D + 1, j) = sd.y, RAY_F(PF_D + 2, j) = sd.z;
           SLOT_F(PF_STRENGTH, j) = 1.f, SLOT_F(PF_STRENGTH + 1, j) = 1.f, SLOT_F(PF_STRENGTH + 2, j) = 1.f;
           if (!cm.scratch) SLOT_F(PF_COL, j) = col.x, SLOT_F(PF_COL + 1, j) = col.y, SLOT_F(PF_COL + 2, j) = col.z;
           SLOT_U(PF_BOUNCES, j) = 0u, SLOT_U(PF_SAMPLE, j) = s;
@@ -585,8 +606,8 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           const uint32_t r = lane_rank(m_idle);
           if (!have_ray && r < got) {
             my_slot = tlist[t_count - 1u - r];
-            o = mk(SLOT_F(PF_O, my_slot), SLOT_F(PF_O + 1, my_slot), SLOT_F(PF_O + 2, my_slot));
-            d = mk(SLOT_F(PF_D, my_slot), SLOT_F(PF_D + 1, my_slot), SLOT_F(PF_D + 2, my_slot));
+            o = mk(RAY_F(PF_O, my_slot), RAY_F(PF_O + 1, my_slot), RAY_F(PF_O + 2, my_slot));
+            d = mk(RAY_F(PF_D, my_slot), RAY_F(PF_D + 1, my_slot), RAY_F(PF_D + 2, my_slot));
             inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);  // aabb.rs:17
             sgn_x = inv.x < 0.f ? 0u : 4u, sgn_y = inv.y < 0.f ? 12u : 16u, sgn_z = inv.z < 0.f ? 24u : 28u;  // aabb.rs:20-23
             pc = pc0, best = F32_MAX, best_pc = NO_HIT, best_flags = 0;
@@ -675,6 +696,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
 #undef RT_FETCH_MAT
 #undef SLOT_U
 #undef SLOT_F
+#undef RAY_F
 }
 
 }  // namespace rtg

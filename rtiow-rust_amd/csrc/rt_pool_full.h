@@ -19,6 +19,10 @@
 
 namespace rtg {
 
+#ifndef RT_FULL_POOL_SLOTS
+#define RT_FULL_POOL_SLOTS 160  // 128: gather points and slow passes run short of waiting lanes (book-2 +15 %); 192: +2.5 %
+#endif
+constexpr uint32_t FPOOL = RT_FULL_POOL_SLOTS;  // path slots per wave of the full-feature kernel (24 dwords each)
 constexpr uint32_t FPOOL_FIELDS = 24;
 enum FullPoolField : uint32_t {
   FF_O = 0, FF_D = 3, FF_TIME = 6, FF_HITMAT = 7, FF_P = 8, FF_N = 11, FF_STRENGTH = 14, FF_ACCUM = 17, FF_BOUNCES = 20,
@@ -27,7 +31,7 @@ enum FullPoolField : uint32_t {
 
 // LDS = the first `window` program records (all of them when the program fits, 0 = none) + the lists
 inline size_t full_pool_lds_bytes(uint32_t window, uint32_t waves) {
-  return (size_t)window * 32 + (((size_t)waves * POOL * 3 * 2 + 15) & ~(size_t)15);  // T-, S- and X-list (u16 slot ids)
+  return (size_t)window * 32 + (((size_t)waves * FPOOL * 3 * 2 + 15) & ~(size_t)15);  // T-, S- and X-list (u16 slot ids)
 }
 
 // draw `idx` (0-based) of the stream (seed, pixel, sample, event): word idx%4 of Philox block idx/4
@@ -77,15 +81,15 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
 #define RT_FETCH_HI(pc_) (RT_IN_LDS(pc_) ? *reinterpret_cast<const uint4*>(s_bytes + win_bytes + (pc_)) : fetch_hi_global(sc, (pc_) >> 4))
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, n_waves = blockDim.x >> 6;
   const size_t gwave = (size_t)blockIdx.x * n_waves + wave;
-  uint32_t* slot = g_slots + gwave * (POOL * FPOOL_FIELDS);
+  uint32_t* slot = g_slots + gwave * (FPOOL * FPOOL_FIELDS);
   float* slotf = reinterpret_cast<float*>(slot);
   float* stack = g_stack + gwave * (MAX_XFORM_DEPTH * 6 * 64);  // [level][component][lane]
-  uint16_t* tlist = reinterpret_cast<uint16_t*>(s_mem + staged) + wave * (3u * POOL);
-  uint16_t* slist = tlist + POOL;  // finished rays whose material needs no texture lookup (and slots without a ray)
-  uint16_t* xlist = slist + POOL;  // finished rays that hit a checker / Perlin textured material
-#define SLOT_U(f_, j_) slot[(f_)*POOL + (j_)]
-#define SLOT_F(f_, j_) slotf[(f_)*POOL + (j_)]
-  for (uint32_t j = lane; j < POOL; j += 64u) {
+  uint16_t* tlist = reinterpret_cast<uint16_t*>(s_mem + staged) + wave * (3u * FPOOL);
+  uint16_t* slist = tlist + FPOOL;  // finished rays whose material needs no texture lookup (and slots without a ray)
+  uint16_t* xlist = slist + FPOOL;  // finished rays that hit a checker / Perlin textured material
+#define SLOT_U(f_, j_) slot[(f_)*FPOOL + (j_)]
+#define SLOT_F(f_, j_) slotf[(f_)*FPOOL + (j_)]
+  for (uint32_t j = lane; j < FPOOL; j += 64u) {
     SLOT_U(FF_HITMAT, j) = SLOT_NEED_PIXEL;
     slist[j] = (uint16_t)j;
   }
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
 
   const uint64_t seed = ((uint64_t)P.seed_hi << 32) | P.seed_lo;
   const float t_near = P.t_near;
-  uint32_t t_count = 0, s_count = POOL, x_count = 0, n_dead = 0;
+  uint32_t t_count = 0, s_count = FPOOL, x_count = 0, n_dead = 0;
   uint32_t w_next = 0, w_end = 0, w_chunk = 0, w_delta = 0;
   bool w_lpt_ready = false;
   bool exhausted = false;
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
             if (COUNT) total_draws += rng.draws;
             if (ended) {
               float* sp = cm.scratch + 3ull * ((size_t)s * cm.pix_work + pixel_to_work(P, x, row));
-              sp[0] = result.x, sp[1] = result.y, sp[2] = result.z;
+              RT_SCRATCH_STORE(sp, result);
               s++;
               st = (s == P.ns || s % cm.chunk == 0u) ? ST_NEED_PIXEL : ST_GEN;
             } else {
@@ -461,7 +465,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         }
       }
       if (COUNT) t_serv += RT_TICK() - t_mark;
-      if (n_dead == POOL) break;
+      if (n_dead == FPOOL) break;
       if (__builtin_amdgcn_ballot_w64(have_ray) == 0) continue;
       op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
     }

@@ -168,6 +168,7 @@ struct rtg_scene {
   uint32_t* d_lpt = nullptr;   // cost-ordered work queue (rt_pool.h LptQueue)
   size_t lpt_bytes = 0;
   LptQueue lpt_desc{};         // what the descriptor slot of d_lpt holds
+  int ray_lds = 1;             // RTG_RAY_LDS=0: all slot fields in global memory
   int lpt = 2;                 // RTG_LPT=0: natural order throughout; 1 / 2 = LptQueue::mode
   int lpt_deep = 6;            // RTG_LPT_DEEP: scatter events at bounce >= this make up a block's cost
   int lpt_shift = 0;           // RTG_LPT_SHIFT: merge cost classes in groups of 1 << shift
@@ -263,11 +264,13 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
   hipError_t e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream);  // re-initialise every call
   if (e != hipSuccess) return e;
   const size_t lds_limit = 160 * 1024;
-  bool use_lds = pool_lds_bytes(s->n_prog, s->n_mat, waves, true) <= lds_limit;
-  size_t lds = pool_lds_bytes(s->n_prog, s->n_mat, waves, use_lds);
+  bool use_lds = pool_lds_bytes(s->n_prog, s->n_mat, waves, true, false) <= lds_limit;
+  bool ray_lds = s->ray_lds && pool_lds_bytes(s->n_prog, s->n_mat, waves, use_lds, true) <= lds_limit;
+  size_t lds = pool_lds_bytes(s->n_prog, s->n_mat, waves, use_lds, ray_lds);
   void (*kernel)(DevScene, DevCamera, DevParams, float*, uint32_t, uint32_t*, unsigned long long*, PoolTuning, ChunkMode,
                  uint32_t*);
-  kernel = use_lds ? render_lean_pool<true, COUNT> : render_lean_pool<false, COUNT>;
+  if (ray_lds) kernel = use_lds ? render_lean_pool<true, COUNT, true> : render_lean_pool<false, COUNT, true>;
+  else kernel = use_lds ? render_lean_pool<true, COUNT, false> : render_lean_pool<false, COUNT, false>;
   e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   int per_cu = s->wg_per_cu;
@@ -282,8 +285,8 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
   e = setup_lpt(s, cm, (uint64_t)grid * waves * POOL, stream);
   if (e != hipSuccess) return e;
   if (getenv("RTG_VERBOSE"))
-    fprintf(stderr, "[rtg] pool: grid %u x %d threads, %d WG/CU, lds %zu B (program staged: %d), %u chunk(s) of %u samples\n", grid,
-            bt, per_cu, lds, (int)use_lds, cm.n_chunks, cm.chunk);
+    fprintf(stderr, "[rtg] pool: grid %u x %d threads, %d WG/CU, lds %zu B (program staged: %d, rays in LDS: %d), %u chunk(s) of %u samples\n", grid,
+            bt, per_cu, lds, (int)use_lds, (int)ray_lds, cm.n_chunks, cm.chunk);
   {
     size_t need = (size_t)grid * waves * POOL * POOL_FIELDS * sizeof(uint32_t);
     if (need > s->slots_bytes) {
@@ -400,11 +403,11 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
     if (e != hipSuccess) return e;
   }
   if (per_cu < 1) per_cu = 1;
-  uint64_t want = (total_work + (uint64_t)waves * POOL - 1) / ((uint64_t)waves * POOL);
+  uint64_t want = (total_work + (uint64_t)waves * FPOOL - 1) / ((uint64_t)waves * FPOOL);
   uint32_t grid = (uint32_t)std::min<uint64_t>(want ? want : 1, (uint64_t)s->num_cus * per_cu);
-  e = setup_lpt(s, cm, (uint64_t)grid * waves * POOL, stream);
+  e = setup_lpt(s, cm, (uint64_t)grid * waves * FPOOL, stream);
   if (e != hipSuccess) return e;
-  e = grow((void**)&s->d_slots, &s->slots_bytes, (size_t)grid * waves * POOL * FPOOL_FIELDS * sizeof(uint32_t));
+  e = grow((void**)&s->d_slots, &s->slots_bytes, (size_t)grid * waves * FPOOL * FPOOL_FIELDS * sizeof(uint32_t));
   if (e != hipSuccess) return e;
   e = grow((void**)&s->d_stack, &s->stack_bytes, (size_t)grid * waves * MAX_XFORM_DEPTH * 6 * 64 * sizeof(float));
   if (e != hipSuccess) return e;
@@ -755,6 +758,7 @@ int rtg_scene_create(rtg_builder* b, const rtg_id* world, size_t n, int device, 
   if (const char* kv = getenv("RTG_KERNEL")) s->kernel_version = atoi(kv);  // A/B switches for measurements
   if (const char* kv = getenv("RTG_CHUNKS")) s->force_chunks = atoi(kv);
   if (const char* kv = getenv("RTG_LPT")) s->lpt = atoi(kv);
+  if (const char* kv = getenv("RTG_RAY_LDS")) s->ray_lds = atoi(kv);
   if (const char* kv = getenv("RTG_LPT_PHASE1")) s->lpt_phase1 = atoi(kv);
   if (const char* kv = getenv("RTG_LPT_DEEP")) s->lpt_deep = atoi(kv);
   if (const char* kv = getenv("RTG_LPT_SHIFT")) s->lpt_shift = std::min(6, std::max(0, atoi(kv)));
