@@ -189,16 +189,18 @@ struct PoolTuning {
   uint32_t gather_min;   // full-feature kernel: lanes waiting at an F_GATHER record before they are released together
 };
 
-// LDS image of the program (staged variant): one 48-byte record per instruction, pc = 48 r.
-//   BOX     dw0-2 (max.x, min.x, max.x)  dw3-5 (max.y, min.y, max.y)  dw6-8 (max.z, min.z, max.z)
-//           dw10 skip pc   dw11 op/flags | LDS_BOX_BIT
-//   others  dw0-3 = lo, dw4-7 = hi, dw11 = op/flags
+// LDS image of the program (staged variant): one 56-byte record per instruction, pc = 56 r.
+//   BOX     dw0-5  (min.x, max.x) (min.y, max.y) (min.z, max.z)     the pairs a ray with 1/d >= 0 wants
+//           dw6-11 (max.x, min.x) (max.y, min.y) (max.z, min.z)     ... and one with 1/d < 0
+//           dw12 skip pc   dw13 op/flags | LDS_BOX_BIT
+//   others  dw0-3 = lo, dw4-7 = hi, dw13 = op/flags
 // pc is the record's absolute LDS address (a step forms no base + offset sum); "is this a BOX" is the
 // sign bit of the flag word (one compare, no mask).
-// Aabb::hit swaps (t0, t1) when 1/d < 0 (aabb.rs:20-23).  With the plane triple (max, min, max) a lane
-// reads ITS (near plane, far plane) pair with one 8-byte load at byte 4 (1/d >= 0: (min, max)) or byte 0
-// (1/d < 0: (max, min)); the offset is fixed per ray, so the swap costs no instruction per step.
-constexpr uint32_t LDS_REC = 48;
+// Aabb::hit swaps (t0, t1) when 1/d < 0 (aabb.rs:20-23).  A lane reads ITS (near plane, far plane) pair
+// per axis with one ALIGNED 8-byte load (ds_read_b64: 2 LDS cycles per wave, against 4 for the
+// ds_read2_b32 an unaligned pair needs -- the box loop runs the LDS pipe at ~80 %); the offset is
+// fixed per ray, so the swap costs no instruction per step.
+constexpr uint32_t LDS_REC = 56;
 constexpr uint32_t LDS_BOX_BIT = 0x80000000u;
 typedef __attribute__((address_space(3))) const char* lds_cptr;
 
@@ -206,7 +208,7 @@ typedef __attribute__((address_space(3))) const char* lds_cptr;
 // global memory (L2-resident; a field access of 64 lanes touches at most 4 cache lines), which leaves
 // LDS to the program and lets 16 waves share a CU.
 inline size_t pool_lds_bytes(uint32_t n_prog, uint32_t n_mat, uint32_t waves, bool stage_program, bool ray_lds) {
-  size_t b = stage_program ? ((size_t)n_prog * LDS_REC + (size_t)n_mat * 32) : 0;
+  size_t b = stage_program ? ((size_t)n_prog * LDS_REC + (size_t)n_mat * 16) : 0;  // records + (albedo | emission, param) per material
   b += (size_t)waves * POOL * 3 * 2;  // T-, S- and E-list (u16 slot ids)
   b = (b + 15) & ~(size_t)15;
   if (ray_lds) b += (size_t)waves * POOL * 6 * sizeof(float);  // the slots' rays (o, d)
@@ -214,12 +216,12 @@ inline size_t pool_lds_bytes(uint32_t n_prog, uint32_t n_mat, uint32_t waves, bo
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef f32x2 f32x2_a4 __attribute__((aligned(4)));   // 4-byte aligned pair: lowers to ds_read2_b32
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define RT_AS3(type_, addr_) (*(const __attribute__((address_space(3))) type_*)(uintptr_t)(addr_))
-RT_DEV uint4 lds_u4(uint32_t a) {  // ds_read_b128 at an absolute LDS address
-  const u32x4 v = RT_AS3(u32x4, a);
+typedef u32x4 u32x4_a8 __attribute__((aligned(8)));
+RT_DEV uint4 lds_u4(uint32_t a) {  // 16 bytes at an 8-byte aligned absolute LDS address (ds_read2_b64)
+  const u32x4 v = RT_AS3(u32x4_a8, a);
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
@@ -263,31 +265,36 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
   // BOX skip pointers are stored pre-multiplied).  Not staged (program larger than LDS): REC = 16 and
   // (lo, hi) come from global memory.
   constexpr uint32_t REC = USE_LDS ? LDS_REC : 16u;
-  const uint32_t staged = USE_LDS ? 3u * n_prog + 2u * sc.n_mat : 0u;  // uint4 units
+  const uint32_t staged = USE_LDS ? LDS_REC * n_prog + 16u * sc.n_mat : 0u;  // bytes
+  uint32_t* s_words = reinterpret_cast<uint32_t*>(s_mem);
   const uint32_t pc0 = USE_LDS ? (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)s_mem : 0u;  // pc of record 0
   if (USE_LDS) {
     for (uint32_t i = threadIdx.x; i < n_prog; i += blockDim.x) {
       const uint4 l = sc.lo[i], h = sc.hi[i];
-      uint4 a = l, b = h, c = make_uint4(0u, 0u, 0u, h.w);
+      uint32_t* r = s_words + 14u * i;
+      r[0] = l.x, r[1] = l.y, r[2] = l.z, r[3] = l.w, r[4] = h.x, r[5] = h.y, r[6] = h.z, r[7] = h.w;
+      r[12] = 0u, r[13] = h.w;
       if ((h.w & 0xffu) == OP_BOX) {  // lo = (min.x, max.x, min.y, max.y), hi = (min.z, max.z, skip, flags)
-        a = make_uint4(l.y, l.x, l.y, l.w);
-        b = make_uint4(l.z, l.w, h.y, h.x);
-        c = make_uint4(h.y, 0u, pc0 + h.z * LDS_REC, h.w | LDS_BOX_BIT);
+        r[6] = l.y, r[7] = l.x, r[8] = l.w, r[9] = l.z, r[10] = h.y, r[11] = h.x;
+        r[12] = pc0 + h.z * LDS_REC, r[13] = h.w | LDS_BOX_BIT;
       }
-      s_mem[3u * i] = a, s_mem[3u * i + 1u] = b, s_mem[3u * i + 2u] = c;
     }
-    for (uint32_t i = threadIdx.x; i < 2u * sc.n_mat; i += blockDim.x) s_mem[3u * n_prog + i] = sc.mat[i];
+    for (uint32_t i = threadIdx.x; i < sc.n_mat; i += blockDim.x) {
+      const uint4 m = sc.mat[2u * i];
+      uint32_t* r = s_words + 14u * n_prog + 4u * i;
+      r[0] = m.x, r[1] = m.y, r[2] = m.z, r[3] = m.w;
+    }
   }
 #define RT_FETCH_LO(pc_) (USE_LDS ? lds_u4(pc_) : sc.lo[(pc_) >> 4])
 #define RT_FETCH_HI(pc_) (USE_LDS ? lds_u4((pc_) + 16u) : fetch_hi_global(sc, (pc_) >> 4))
-#define RT_FETCH_MAT(i_) (USE_LDS ? s_mem[3u * n_prog + (i_)] : sc.mat[(i_)])
+#define RT_FETCH_MATLO(i_) (USE_LDS ? lds_u4(pc0 + LDS_REC * n_prog + 16u * (i_)) : sc.mat[2u * (i_)])
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, n_waves = blockDim.x >> 6;
   uint32_t* slot = g_slots + ((size_t)blockIdx.x * n_waves + wave) * (POOL * POOL_FIELDS);
   float* slotf = reinterpret_cast<float*>(slot);
-  uint16_t* tlist = reinterpret_cast<uint16_t*>(s_mem + staged) + wave * (3u * POOL);
+  uint16_t* tlist = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(s_mem) + staged) + wave * (3u * POOL);
   uint16_t* slist = tlist + POOL;
   uint16_t* elist = slist + POOL;
-  float* lds_ray = reinterpret_cast<float*>(reinterpret_cast<char*>(s_mem + staged) + (((size_t)n_waves * POOL * 6u + 15u) & ~(size_t)15u)) +
+  float* lds_ray = reinterpret_cast<float*>(reinterpret_cast<char*>(s_mem) + (((size_t)staged + n_waves * POOL * 6u + 15u) & ~(size_t)15u)) +
                    (size_t)wave * (POOL * 6u);
 #define SLOT_U(f_, j_) slot[(f_)*POOL + (j_)]
 #define SLOT_F(f_, j_) slotf[(f_)*POOL + (j_)]
@@ -328,10 +335,10 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
   // load the record at pc into (cx, cy, cz, c_skip, c_flags)
 #define RT_LOAD_REC() \
         if (USE_LDS) { \
-          cx = RT_AS3(f32x2_a4, pc + sgn_x); \
-          cy = RT_AS3(f32x2_a4, pc + sgn_y); \
-          cz = RT_AS3(f32x2_a4, pc + sgn_z); \
-          const u32x2 sf_ = RT_AS3(u32x2, pc + 40u); \
+          cx = RT_AS3(f32x2, pc + sgn_x); \
+          cy = RT_AS3(f32x2, pc + sgn_y); \
+          cz = RT_AS3(f32x2, pc + sgn_z); \
+          const u32x2 sf_ = RT_AS3(u32x2, pc + 48u); \
           c_skip = sf_.x, c_flags = sf_.y; \
         } else { \
           const uint4 l_ = sc.lo[pc >> 4], h_ = sc.hi[pc >> 4]; \
@@ -410,8 +417,8 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           V3 hn = sdiv(hp, u2f(plo.w));                        // object.rs:104
           if (phi.w & F_TRANSLATE) hp = vadd(hp, off);         // object.rs:279-282
           if (phi.w & F_FLIP) hn = vneg(hn);                   // object.rs:249-252
-          const uint4 mlo = RT_FETCH_MAT(2u * phi.z), mhi = RT_FETCH_MAT(2u * phi.z + 1u);
-          const uint32_t kind = mhi.w & 0xffu;
+          const uint4 mlo = RT_FETCH_MATLO(phi.z);
+          const uint32_t kind = (phi.w >> F_MATKIND_SHIFT) & 7u;  // the flattener's copy of the material kind
           const float param = u2f(mlo.w);
           const V3 mcol = mk(u2f(mlo.x), u2f(mlo.y), u2f(mlo.z));
           // lib.rs:76 with emitted = 0 (material.rs:126): accum stays +0, see PoolField
@@ -508,7 +515,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
                 if (COUNT) cnt.shaded++;
                 const V3 strength = mk(SLOT_F(PF_STRENGTH, j), SLOT_F(PF_STRENGTH + 1, j), SLOT_F(PF_STRENGTH + 2, j));
                 const uint4 phi = RT_FETCH_HI(bpc);
-                const uint4 mlo = RT_FETCH_MAT(2u * phi.z);
+                const uint4 mlo = RT_FETCH_MATLO(phi.z);
                 const V3 emitted = smul(u2f(mlo.w), mk(u2f(mlo.x), u2f(mlo.y), u2f(mlo.z)));  // material.rs:120-128
                 result = vadd(accum, vmul(strength, emitted));
               }
@@ -609,7 +616,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
             o = mk(RAY_F(PF_O, my_slot), RAY_F(PF_O + 1, my_slot), RAY_F(PF_O + 2, my_slot));
             d = mk(RAY_F(PF_D, my_slot), RAY_F(PF_D + 1, my_slot), RAY_F(PF_D + 2, my_slot));
             inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);  // aabb.rs:17
-            sgn_x = inv.x < 0.f ? 0u : 4u, sgn_y = inv.y < 0.f ? 12u : 16u, sgn_z = inv.z < 0.f ? 24u : 28u;  // aabb.rs:20-23
+            sgn_x = inv.x < 0.f ? 24u : 0u, sgn_y = inv.y < 0.f ? 32u : 8u, sgn_z = inv.z < 0.f ? 40u : 16u;  // aabb.rs:20-23
             pc = pc0, best = F32_MAX, best_pc = NO_HIT, best_flags = 0;
             RT_LOAD_REC();
             have_ray = true;
@@ -693,7 +700,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
 #undef RT_IS_BOX
 #undef RT_FETCH_LO
 #undef RT_FETCH_HI
-#undef RT_FETCH_MAT
+#undef RT_FETCH_MATLO
 #undef SLOT_U
 #undef SLOT_F
 #undef RAY_F
