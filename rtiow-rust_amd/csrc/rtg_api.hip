@@ -176,7 +176,7 @@ struct rtg_scene {
   // lean scenes: 3 = ray-pool kernel (rt_pool.h), 2 = persistent single-wave regeneration (rt_persistent.h),
   // 1 = one-lane-per-pixel baseline (rt_trace.h).  Non-lean scenes always use 1.
   int kernel_version = 3;
-  PoolTuning pool_tune{20, 16, 32, 16, 16, 40};
+  PoolTuning pool_tune{36, 16, 32, 16, 16, 40};
   Tuning tune{24, 16, 8};
   int block_threads = 512, wg_per_cu = 0;  // 0 = ask the occupancy API
   int full_threads = 0;                    // full-feature pool kernel: 0 = the variant's maximum (RTG_BLOCK overrides)
