@@ -79,6 +79,9 @@ constexpr uint32_t FEAT_MEDIUM = 2u;   // MEDIUM present
 constexpr uint32_t FEAT_RECT = 4u;     // RECT present
 constexpr uint32_t FEAT_TEXTURE = 8u;  // a non-constant texture is referenced
 constexpr uint32_t FEAT_BOUNDARY = 16u; // a ConstantMedium whose boundary is an object graph (nested boundary walk)
-constexpr uint32_t FEAT_WIDE_ALBEDO = 32u;  // an albedo component outside [0, 1]: path strength is not bounded by 1 (rt_pool.h PoolField)
+constexpr uint32_t FEAT_BRIGHT_ALBEDO = 64u; // an albedo component may exceed 1 (a constant in (1, 4], or Perlin turbulence, <= 3.47): the pool
+                                            // kernels then need max_bounces <= 63 for the strength to stay finite
+constexpr uint32_t FEAT_WIDE_ALBEDO = 32u;  // an albedo component outside [0, 4]: path strength may overflow or change sign, so the pool
+                                            // kernels' "accum is +0" does not hold (rt_pool.h PoolField): baseline kernel
 
 }  // namespace rtg

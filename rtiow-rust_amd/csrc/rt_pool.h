@@ -38,10 +38,10 @@ enum PoolField : uint32_t {
   PF_O = 0, PF_D = 3, PF_BEST = 6, PF_BEST_PC = 7, PF_STRENGTH = 8, PF_BOUNCES = 11, PF_SAMPLE = 12, PF_XY = 13, PF_COL = 14,
 };
 // There is no accum field.  color()'s `accum = accum + strength * emitted` (lib.rs:76) adds
-// strength * 0 at every hit on a scattering material (material.rs:126), and a lean scene has no other
-// emitter than the DiffuseLight that ends the path: with every albedo component in [0, 1] (the
-// flattener routes anything else to the full-feature kernel, FEAT_WIDE_ALBEDO) strength stays in
-// [0, 1], strength * 0 = +0 and accum is +0 whenever it is read.  Six fewer slot rows per pass.
+// strength * 0 at every hit on a scattering material (material.rs:126), and the only emitter, a
+// DiffuseLight, ends the path.  With every albedo component in [0, 4] (Perlin turbulence is <= 2) the
+// strength stays finite and non-negative over 51 bounces, strength * 0 = +0 and accum is +0 whenever
+// it is read; the flattener routes anything else to the baseline kernel (FEAT_WIDE_ALBEDO).
 
 // Sample-chunk mode.  One lane per pixel cannot fill the chip when a rank owns few pixels (8-GPU
 // shards, small images).  A work item is then (pixel, chunk of `chunk` consecutive samples); every

@@ -22,11 +22,11 @@ namespace rtg {
 #ifndef RT_FULL_POOL_SLOTS
 #define RT_FULL_POOL_SLOTS 160  // 128: gather points and slow passes run short of waiting lanes (book-2 +15 %); 192: +2.5 %
 #endif
-constexpr uint32_t FPOOL = RT_FULL_POOL_SLOTS;  // path slots per wave of the full-feature kernel (24 dwords each)
-constexpr uint32_t FPOOL_FIELDS = 24;
+constexpr uint32_t FPOOL = RT_FULL_POOL_SLOTS;  // path slots per wave of the full-feature kernel (21 dwords each)
+constexpr uint32_t FPOOL_FIELDS = 21;
 enum FullPoolField : uint32_t {
-  FF_O = 0, FF_D = 3, FF_TIME = 6, FF_HITMAT = 7, FF_P = 8, FF_N = 11, FF_STRENGTH = 14, FF_ACCUM = 17, FF_BOUNCES = 20,
-  FF_SAMPLE = 21, FF_XY = 22, FF_EVDRAWS = 23,
+  FF_O = 0, FF_D = 3, FF_TIME = 6, FF_HITMAT = 7, FF_P = 8, FF_N = 11, FF_STRENGTH = 14, FF_BOUNCES = 17, FF_SAMPLE = 18, FF_XY = 19,
+  FF_EVDRAWS = 20,
 };
 
 // LDS = the first `window` program records (all of them when the program fits, 0 = none) + the lists
@@ -267,7 +267,10 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         count -= take;
         if (COUNT) n_shade++, n_shade_lanes += take, t_mark2 = RT_TICK();
         uint32_t st = ST_DEAD, j = 0;
-        V3 so = mk(0.f, 0.f, 0.f), sd = so, strength = so, accum = so;
+        V3 so = mk(0.f, 0.f, 0.f), sd = so, strength = so;
+        // no accum field: it is +0 whenever it is read (rt_pool.h PoolField; the host only routes scenes
+        // here whose path strength stays finite and non-negative)
+        V3 accum = so;
         float stime = 0.f;
         uint32_t bounces = 0, s = 0, x = 0, row = 0;
         bool lpt_on = false;
@@ -291,7 +294,6 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
             sd = mk(SLOT_F(FF_D, j), SLOT_F(FF_D + 1, j), SLOT_F(FF_D + 2, j));
             stime = SLOT_F(FF_TIME, j);
             strength = mk(SLOT_F(FF_STRENGTH, j), SLOT_F(FF_STRENGTH + 1, j), SLOT_F(FF_STRENGTH + 2, j));
-            accum = mk(SLOT_F(FF_ACCUM, j), SLOT_F(FF_ACCUM + 1, j), SLOT_F(FF_ACCUM + 2, j));
             bounces = SLOT_U(FF_BOUNCES, j), s = SLOT_U(FF_SAMPLE, j);
             const uint32_t xy = SLOT_U(FF_XY, j);
             x = xy & 0xffffu, row = xy >> 16;
@@ -424,7 +426,6 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           SLOT_F(FF_D, j) = sd.x, SLOT_F(FF_D + 1, j) = sd.y, SLOT_F(FF_D + 2, j) = sd.z;
           SLOT_F(FF_TIME, j) = stime;
           SLOT_F(FF_STRENGTH, j) = strength.x, SLOT_F(FF_STRENGTH + 1, j) = strength.y, SLOT_F(FF_STRENGTH + 2, j) = strength.z;
-          SLOT_F(FF_ACCUM, j) = accum.x, SLOT_F(FF_ACCUM + 1, j) = accum.y, SLOT_F(FF_ACCUM + 2, j) = accum.z;
           SLOT_U(FF_BOUNCES, j) = bounces, SLOT_U(FF_SAMPLE, j) = s;
           SLOT_U(FF_XY, j) = x | (row << 16);
           tlist[t_count + lane_rank(m_live)] = (uint16_t)j;

@@ -176,7 +176,8 @@ struct rtg_scene {
   // lean scenes: 3 = ray-pool kernel (rt_pool.h), 2 = persistent single-wave regeneration (rt_persistent.h),
   // 1 = one-lane-per-pixel baseline (rt_trace.h).  Non-lean scenes always use 1.
   int kernel_version = 3;
-  PoolTuning pool_tune{36, 16, 32, 16, 16, 40};
+  PoolTuning pool_tune{36, 16, 32, 16, 16, 40};  // lean ray-pool kernel
+  PoolTuning full_tune{20, 16, 32, 16, 16, 40};  // full-feature kernel (a service there also has hit records to move)
   Tuning tune{24, 16, 8};
   int block_threads = 512, wg_per_cu = 0;  // 0 = ask the occupancy API
   int full_threads = 0;                    // full-feature pool kernel: 0 = the variant's maximum (RTG_BLOCK overrides)
@@ -415,7 +416,7 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
     fprintf(stderr, "[rtg] full pool: grid %u x %d threads, %d WG/CU, lds %zu B (program window: %u of %u records)\n", grid, bt,
             per_cu, lds, window, s->n_prog);
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(bt), lds, stream, s->dev, cam, d, d_out, (uint32_t)total_work, queue,
-                     s->d_counters, s->pool_tune, cm, s->d_slots, s->d_stack, window);
+                     s->d_counters, s->full_tune, cm, s->d_slots, s->d_stack, window);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(fold_samples_kernel, dim3((uint32_t)((pix_work + 255) / 256)), dim3(256), 0, stream, d, cm, d_out);
@@ -425,16 +426,20 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
 template <bool COUNT>
 static hipError_t launch_render(rtg_scene* s, const DevCamera& cam, const DevParams& d, float* d_out,
                                 hipStream_t stream) {
-  if (s->features != 0 && !(s->features & FEAT_BOUNDARY) && s->kernel_version >= 3 && d.nx <= 0xffffu && d.ny <= 0xffffu) {
+  // geometry / texture features pick the kernel; the albedo-range bits only say whether the pool kernels' "accum
+  // is +0" argument holds (rt_pool.h PoolField)
+  const uint32_t geom = s->features & (FEAT_ALL | FEAT_BOUNDARY);
+  const bool accum_zero = !(s->features & FEAT_WIDE_ALBEDO) && (!(s->features & FEAT_BRIGHT_ALBEDO) || d.max_bounces <= 63u);
+  const bool pool_ok = accum_zero && s->kernel_version >= 3 && d.nx <= 0xffffu && d.ny <= 0xffffu;
+  if (geom != 0 && !(geom & FEAT_BOUNDARY) && pool_ok) {
     hipError_t e = launch_full_pool<COUNT>(s, cam, d, d_out, stream);
     if (e != hipErrorNotSupported) return e;
   }
-  if (s->features == 0 && s->kernel_version >= 3 && d.nx <= 0xffffu && d.ny <= 0xffffu)
-    return launch_pool<COUNT>(s, cam, d, d_out, stream);
-  if (s->features == 0 && s->kernel_version >= 2) return launch_persistent<COUNT>(s, cam, d, d_out, stream);
+  if (geom == 0 && pool_ok) return launch_pool<COUNT>(s, cam, d, d_out, stream);
+  if (geom == 0 && s->kernel_version >= 2) return launch_persistent<COUNT>(s, cam, d, d_out, stream);
   uint32_t nbx = (d.nx + 15) / 16, nby = (d.ny + 15) / 16;
   dim3 grid(nbx * nby), block(256);
-  if (s->features == 0)
+  if (geom == 0)
     hipLaunchKernelGGL((render_kernel<0u, COUNT>), grid, block, 0, stream, s->dev, cam, d, d_out, s->d_counters);
   else
     hipLaunchKernelGGL((render_kernel<FEAT_ALL, COUNT>), grid, block, 0, stream, s->dev, cam, d, d_out, s->d_counters);
@@ -766,12 +771,12 @@ int rtg_scene_create(rtg_builder* b, const rtg_id* world, size_t n, int device, 
   if (const char* kv = getenv("RTG_WG_PER_CU")) s->wg_per_cu = atoi(kv);
   if (const char* kv = getenv("RTG_REGEN_MIN")) s->tune.regen_min = (uint32_t)atoi(kv);
   if (const char* kv = getenv("RTG_SPHERE_MIN")) s->tune.sphere_min = (uint32_t)atoi(kv);
-  if (const char* kv = getenv("RTG_BOX_LEAVE")) s->tune.box_leave = s->pool_tune.box_leave = (uint32_t)atoi(kv);
-  if (const char* kv = getenv("RTG_REFILL_MIN")) s->pool_tune.refill_min = (uint32_t)atoi(kv);
-  if (const char* kv = getenv("RTG_GATHER_MIN")) s->pool_tune.gather_min = (uint32_t)atoi(kv);
-  if (const char* kv = getenv("RTG_RUN_AHEAD")) s->pool_tune.run_ahead = (uint32_t)atoi(kv);
-  if (const char* kv = getenv("RTG_RUN_AHEAD_MIN")) s->pool_tune.run_ahead_min = (uint32_t)atoi(kv);
-  if (const char* kv = getenv("RTG_SPHERE_MIN")) s->pool_tune.sphere_min = (uint32_t)atoi(kv);
+  if (const char* kv = getenv("RTG_BOX_LEAVE")) s->tune.box_leave = s->pool_tune.box_leave = s->full_tune.box_leave = (uint32_t)atoi(kv);
+  if (const char* kv = getenv("RTG_REFILL_MIN")) s->pool_tune.refill_min = s->full_tune.refill_min = (uint32_t)atoi(kv);
+  if (const char* kv = getenv("RTG_GATHER_MIN")) s->pool_tune.gather_min = s->full_tune.gather_min = (uint32_t)atoi(kv);
+  if (const char* kv = getenv("RTG_RUN_AHEAD")) s->pool_tune.run_ahead = s->full_tune.run_ahead = (uint32_t)atoi(kv);
+  if (const char* kv = getenv("RTG_RUN_AHEAD_MIN")) s->pool_tune.run_ahead_min = s->full_tune.run_ahead_min = (uint32_t)atoi(kv);
+  if (const char* kv = getenv("RTG_SPHERE_MIN")) s->pool_tune.sphere_min = s->full_tune.sphere_min = (uint32_t)atoi(kv);
   if (hipMalloc((void**)&s->d_counters, 32 * sizeof(unsigned long long)) != hipSuccess ||
       hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
     rtg_scene_destroy(s);

@@ -430,10 +430,13 @@ void SceneBuilder::flatten(const uint32_t* world, size_t n, FlatScene* out) cons
       tex = m.tex;
       if (t.kind == TEX_CONSTANT) c[0] = t.rgb[0], c[1] = t.rgb[1], c[2] = t.rgb[2];
       else out->features |= FEAT_TEXTURE;
+      if (t.kind == TEX_PERLIN) out->features |= FEAT_BRIGHT_ALBEDO;
     }
     if (m.kind != MAT_DIFFUSE_LIGHT && m.kind != MAT_DIELECTRIC)
-      for (float a : c)
-        if (!(a >= 0.f && a <= 1.f)) out->features |= FEAT_WIDE_ALBEDO;
+      for (float a : c) {
+        if (!(a >= 0.f && a <= 4.f)) out->features |= FEAT_WIDE_ALBEDO;
+        else if (a > 1.f) out->features |= FEAT_BRIGHT_ALBEDO;
+      }
     out->mat.push_back(Packet{{fbits(c[0]), fbits(c[1]), fbits(c[2]), fbits(m.param)}});
     out->mat.push_back(Packet{{tex, 0, 0, m.kind | (texkind << 8)}});
   }

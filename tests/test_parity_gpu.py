@@ -149,6 +149,32 @@ def test_bounce_cap_and_near_are_parameters(pkg, gpu, oracle):
         assert_bit_equal(a, b_, "max_bounces=%d" % mb)
 
 
+def _albedo_scene(pkg, b, albedo, lean):
+    """A mirror-ish pit of high-albedo spheres under a sky dome; `lean` = spheres under one Bvh, else a list
+    world with a rect (full-feature kernel)."""
+    S = pkg.scenes
+    m = b.lambertian(b.constant(S.vfrom(albedo)))
+    objs = [b.translate(S.v(0.0, -100.5, -1.0), b.sphere(100.0, m)), b.translate(S.v(0.0, 0.0, -1.0), b.sphere(0.5, m)),
+            b.translate(S.v(1.0, 0.0, -1.0), b.sphere(0.5, b.metal(S.vfrom(albedo), 0.0))),
+            b.flip_normals(b.sphere(50.0, b.diffuse_light(b.constant(S.v(0.7, 0.8, 1.0)), 1.0)))]
+    world = [b.bvh(objs, (0.0, 1.0))] if lean else objs + [b.rect(1, (-1.0, 1.0), (-2.0, 0.0), 1.5, m)]
+    cam = b.be.camera_look(S.v(-2, 2, 1), S.v(0, 0, -1), S.v(0.0, 1.0, 0.0), 40.0, 1.5, 0.0, 1.0)
+    return b.scene(world), cam
+
+
+@pytest.mark.parametrize("lean", [True, False])
+@pytest.mark.parametrize("albedo,max_bounces", [(1.0, 50), (1.5, 50), (1.5, 200), (3.9, 63), (3.9, 64), (7.0, 50), (-0.5, 50)])
+def test_albedo_range_routing(pkg, gpu, oracle, lean, albedo, max_bounces):
+    """The pool kernels keep no accum (it is provably +0 while the path strength stays finite and non-negative);
+    scenes or bounce caps outside that argument run on the baseline kernel.  Either way: the oracle's bits
+    (albedo 7 overflows the strength to inf, albedo < 0 makes strength * 0 = -0)."""
+    sg, cam_g = _albedo_scene(pkg, gpu.builder(), albedo, lean)
+    so, cam_o = _albedo_scene(pkg, oracle.builder(), albedo, lean)
+    a = sg.par_cast(cam_g, 36, 24, 6, max_bounces=max_bounces)
+    b_ = so.par_cast(cam_o, 36, 24, 6, max_bounces=max_bounces)
+    assert_bit_equal(a, b_, "albedo %g, %d bounces, lean=%s" % (albedo, max_bounces, lean))
+
+
 # ---- BASELINE.json full sizes: size-independent properties + oracle bands ---------------------------------
 def _band(scene, cam, nx, ny, ns, band, nbands, **kw):
     """Render only the `band`-th group of 16 rows (tile_w = nx, tile_h = 16, rank = band)."""
