@@ -492,9 +492,11 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         if (op == OP_BOX) {  // Aabb::hit, aabb.rs:16-27 (1/d and its sign re-read: d changes under RotateY/Scale)
           if (COUNT) cnt.aabb++;
           if (hi_is_root(cur_hi)) root_hits = nhits;
-          const f32x2 tx = (f32x2{u2f(cur_lo.x), u2f(cur_lo.y)} - f32x2{o.x, o.x}) * f32x2{inv.x, inv.x};
-          const f32x2 ty = (f32x2{u2f(cur_lo.z), u2f(cur_lo.w)} - f32x2{o.y, o.y}) * f32x2{inv.y, inv.y};
-          const f32x2 tz = (f32x2{u2f(cur_hi.x), u2f(cur_hi.y)} - f32x2{o.z, o.z}) * f32x2{inv.z, inv.z};
+          // plain f32 math: packed v_pk_* instructions are slower than the pairs they replace on gfx950 (rt_pool.h RT_PK_MATH)
+          f32x2 tx, ty, tz;
+          tx.x = (u2f(cur_lo.x) - o.x) * inv.x, tx.y = (u2f(cur_lo.y) - o.x) * inv.x;
+          ty.x = (u2f(cur_lo.z) - o.y) * inv.y, ty.y = (u2f(cur_lo.w) - o.y) * inv.y;
+          tz.x = (u2f(cur_hi.x) - o.z) * inv.z, tz.y = (u2f(cur_hi.y) - o.z) * inv.z;
           float ax = inv.x < 0.f ? tx.y : tx.x, bx = inv.x < 0.f ? tx.x : tx.y;
           float ay = inv.y < 0.f ? ty.y : ty.x, by = inv.y < 0.f ? ty.x : ty.y;
           float az = inv.z < 0.f ? tz.y : tz.x, bz = inv.z < 0.f ? tz.x : tz.y;
