@@ -247,9 +247,6 @@ RT_DEV uint4 fetch_hi_global(const DevScene& sc, uint32_t idx) {  // byte-offset
 #define RT_PK_MATH 0  // packed f32 math is an anti-lever on gfx950: 6 v_pk_* per box step cost more than the 12 plain
                       // instructions they replace (C2 8.56 -> 8.11 ms) and tie up 6 more VGPRs for the duplicated operands
 #endif
-#ifndef RT_BOX_PREFETCH
-#define RT_BOX_PREFETCH 0  // measured +10 % on C2: twice the LDS reads and 4 more VALU per step outweigh the latency they hide
-#endif
 // Two wait lists, two pass types.  A finished ray is classified by what its path does next:
 //   E ("end")     the path ends here: a miss, a DiffuseLight hit (the sky dome ends 38 % of book-1's
 //                 rays), a path ended by a SCATTER pass, or a slot without a ray.  The END pass books the
@@ -653,71 +650,6 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
       const uint32_t n0 = (uint32_t)__builtin_popcountll(b_box);
       const uint32_t floor_lanes = n0 > tune.box_leave ? n0 - tune.box_leave : 0u;
       uint32_t n_now;
-#if RT_BOX_PREFETCH
-      if (USE_LDS) {
-        // Double step with the sequential successor prefetched.  A step's next record is pc + REC when the
-        // box is hit (56 % of book-1's steps) and that address does not depend on the test: its loads are
-        // issued BEFORE the arithmetic, into a second register set that is live only inside this loop, and
-        // only the lanes that miss reload (the skip target) afterwards.  Step 1 works on the canonical set
-        // (cx, cy, cz, c_skip, c_flags) and leaves the current record in the second set, step 2 the other
-        // way round, so no register is ever copied -- except the flag word of a lane that left the BOX
-        // state in step 1.  (The record after the END record is the first material: a harmless read.)
-        // (inline asm: the compiler would sink the prefetch into the hit branch, i.e. behind the test it is
-        // meant to overlap; it does not track asm loads, hence the explicit s_waitcnt that hands the values over)
-#define RT_LDS_REC4(x_, y_, z_, sf_, base_) \
-        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7 offset:48" \
-                     : "=&v"(x_), "=&v"(y_), "=&v"(z_), "=&v"(sf_) \
-                     : "v"((base_) + sgn_x), "v"((base_) + sgn_y), "v"((base_) + sgn_z), "v"(base_))
-#define RT_LDS_WAIT4(x_, y_, z_, sf_) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x_), "+v"(y_), "+v"(z_), "+v"(sf_))
-        u32x2 c_sf = {c_skip, c_flags}, d_sf = {0u, 0u};
-        f32x2 dx = {0.f, 0.f}, dy = dx, dz = dx;
-        do {
-          if (COUNT) n_box_it++;
-          const bool step1 = (int32_t)c_sf.y < 0;
-          if (step1) {
-            if (COUNT) cnt.aabb++;
-            const uint32_t nx = pc + REC;
-            RT_LDS_REC4(dx, dy, dz, d_sf, nx);
-            const f32x2 tx = (cx - f32x2{o.x, o.x}) * f32x2{inv.x, inv.x};
-            const f32x2 ty = (cy - f32x2{o.y, o.y}) * f32x2{inv.y, inv.y};
-            const f32x2 tz = (cz - f32x2{o.z, o.z}) * f32x2{inv.z, inv.z};
-            const float start = rs_max(t_near, rs_max(rs_max(tx.x, ty.x), tz.x));
-            const float end = rs_min(best, rs_min(rs_min(tx.y, ty.y), tz.y));
-            if (end > start) {
-              pc = nx;
-            } else {
-              pc = c_sf.x;
-              RT_LDS_REC4(dx, dy, dz, d_sf, pc);
-            }
-            RT_LDS_WAIT4(dx, dy, dz, d_sf);
-          }
-          if (step1 && (int32_t)d_sf.y < 0) {
-            if (COUNT) cnt.aabb++;
-            const uint32_t nx = pc + REC;
-            RT_LDS_REC4(cx, cy, cz, c_sf, nx);
-            const f32x2 tx = (dx - f32x2{o.x, o.x}) * f32x2{inv.x, inv.x};
-            const f32x2 ty = (dy - f32x2{o.y, o.y}) * f32x2{inv.y, inv.y};
-            const f32x2 tz = (dz - f32x2{o.z, o.z}) * f32x2{inv.z, inv.z};
-            const float start = rs_max(t_near, rs_max(rs_max(tx.x, ty.x), tz.x));
-            const float end = rs_min(best, rs_min(rs_min(tx.y, ty.y), tz.y));
-            if (end > start) {
-              pc = nx;
-            } else {
-              pc = d_sf.x;
-              RT_LDS_REC4(cx, cy, cz, c_sf, pc);
-            }
-            RT_LDS_WAIT4(cx, cy, cz, c_sf);
-          } else if (step1) {
-            c_sf.y = d_sf.y;  // left the BOX state in step 1: only the flag word of a non-BOX record is ever looked at
-          }
-          n_now = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64((int32_t)c_sf.y < 0));
-          if (COUNT) n_box_lanes += n_now;
-        } while (n_now > floor_lanes);
-        c_skip = c_sf.x, c_flags = c_sf.y;
-#undef RT_LDS_REC4
-#undef RT_LDS_WAIT4
-      } else
-#endif
       do {
         if (COUNT) n_box_it++;
         RT_BOX_STEP();

@@ -170,7 +170,7 @@ struct rtg_scene {
   LptQueue lpt_desc{};         // what the descriptor slot of d_lpt holds
   int ray_lds = 1;             // RTG_RAY_LDS=0: all slot fields in global memory
   int lpt = 2;                 // RTG_LPT=0: natural order throughout; 1 / 2 = LptQueue::mode
-  int lpt_deep = 6;            // RTG_LPT_DEEP: scatter events at bounce >= this make up a block's cost
+  int lpt_deep = 4;            // RTG_LPT_DEEP: scatter events at bounce >= this make up a block's cost
   int lpt_shift = 0;           // RTG_LPT_SHIFT: merge cost classes in groups of 1 << shift
   int lpt_phase1 = 0;          // RTG_LPT_PHASE1: chunks in natural order, 0 = n_chunks / 8 clamped to [2, 8]
   // lean scenes: 3 = ray-pool kernel (rt_pool.h), 2 = persistent single-wave regeneration (rt_persistent.h),
