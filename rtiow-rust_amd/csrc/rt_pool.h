@@ -642,8 +642,13 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
       op = have_ray ? (c_flags & 0xffu) : 0xffu;
     }
     // ============================== TRAVERSE ======================================================
-    const uint64_t b_box = __builtin_amdgcn_ballot_w64(op == OP_BOX);
-    const uint64_t b_sph = __builtin_amdgcn_ballot_w64(op == OP_SPHERE);
+    // box runs and sphere passes alternate in this inner loop until a service is due (the same test as at
+    // the top): the big SERVICE block stays out of the cycle the wave spends its time in
+    // (at least one box run or sphere pass per visit: after a service that found nothing to refill the test
+    // still says "service" although there is nothing to service)
+    uint64_t b_box = __builtin_amdgcn_ballot_w64(op == OP_BOX);
+    uint64_t b_sph = __builtin_amdgcn_ballot_w64(op == OP_SPHERE);
+    for (;;) {
     if (b_box != 0 && (uint32_t)__builtin_popcountll(b_sph) < tune.sphere_min) {
       // box run: tight loop, schedule re-evaluated once `box_leave` lanes have left the BOX state
       if (COUNT) t_mark = RT_TICK();
@@ -683,6 +688,12 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
         RT_LOAD_REC();
       }
       if (COUNT) t_sph += RT_TICK() - t_mark;
+    }
+    op = have_ray ? (c_flags & 0xffu) : 0xffu;
+    b_box = __builtin_amdgcn_ballot_w64(op == OP_BOX);
+    b_sph = __builtin_amdgcn_ballot_w64(op == OP_SPHERE);
+    const uint32_t busy = (uint32_t)__builtin_popcountll(b_box | b_sph);
+    if (64u - busy >= tune.refill_min || busy == 0) break;
     }
   }
   if (COUNT) {
