@@ -471,6 +471,8 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
       op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
     }
     // ============================== TRAVERSE ======================================================
+    // box runs and slow passes alternate in this inner loop until a service is due (rt_pool.h)
+    for (;;) {
     const uint64_t b_box = __builtin_amdgcn_ballot_w64(op == OP_BOX);
     // Lanes at a gather point (head of a list-level run of records every ray executes in the same order)
     // are held until `gather_min` of them wait there -- or nothing else can run -- and then walk the run
@@ -529,6 +531,10 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
       if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op >= OP_SPHERE && op <= OP_PRISM)) < tune.run_ahead_min) break;
       }
       if (COUNT) t_slow += RT_TICK() - t_mark;
+    }
+    op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
+    const uint32_t busy = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op >= OP_BOX && op <= OP_PRISM));
+    if (64u - busy >= tune.refill_min || busy == 0) break;
     }
   }
   if (COUNT) {
