@@ -439,11 +439,16 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           // this event (reflect() consumes no randomness): ONE rejection loop serves all three.
           V3 rs = mk(0.f, 0.f, 0.f);
           if (kind != MAT_DIELECTRIC) rs = in_unit_sphere(rng);
+          // |d| and unit(d) once for the Metal and the Dielectric lanes of the pass (vec3.rs:59,66): the two
+          // branches below are exclusive, the wave usually runs both, and a sqrt + three divides is what they share
+          float sd_len = 0.f;
+          V3 sd_unit = sd;
+          if (kind == MAT_METAL || kind == MAT_DIELECTRIC) sd_len = vlen(sd), sd_unit = sdiv(sd, sd_len);
           if (kind == MAT_LAMBERTIAN) {  // material.rs:57-65
             V3 target = vadd(vadd(hp, hn), rs);
             nd = vsub(target, hp);
           } else if (kind == MAT_METAL) {  // material.rs:66-80
-            V3 refl = reflect(vunit(sd), hn);
+            V3 refl = reflect(sd_unit, hn);
             nd = vadd(refl, smul(param, rs));
             scattered = vdot(nd, hn) > 0.f;
           } else if (kind == MAT_DIELECTRIC) {  // material.rs:81-107
@@ -453,13 +458,13 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
             if (dn > 0.f) {
               outward = vneg(hn);
               ni_over_nt = param;
-              cosine = param * dn / vlen(sd);
+              cosine = param * dn / sd_len;
             } else {
               outward = hn;
               ni_over_nt = 1.0f / param;
-              cosine = -dn / vlen(sd);
+              cosine = -dn / sd_len;
             }
-            V3 uv = vunit(sd);  // refract, vec3.rs:321-330
+            V3 uv = sd_unit;  // refract, vec3.rs:321-330
             float dt = vdot(uv, outward);
             float disc = 1.0f - ni_over_nt * ni_over_nt * (1.f - dt * dt);
             bool refracted = disc > 0.f;

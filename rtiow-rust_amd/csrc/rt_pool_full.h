@@ -316,11 +316,14 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
               bool scattered = true;
               V3 rs = mk(0.f, 0.f, 0.f);
               if (kind == MAT_LAMBERTIAN || kind == MAT_METAL || kind == MAT_ISOTROPIC) rs = in_unit_sphere(rng);
+              float sd_len = 0.f;  // |d| and unit(d) once for the Metal and the Dielectric lanes (rt_pool.h)
+              V3 sd_unit = sd;
+              if (kind == MAT_METAL || kind == MAT_DIELECTRIC) sd_len = vlen(sd), sd_unit = sdiv(sd, sd_len);
               if (kind == MAT_LAMBERTIAN) {
                 V3 target = vadd(vadd(p, n), rs);
                 nd = vsub(target, p);
               } else if (kind == MAT_METAL) {
-                V3 refl = reflect(vunit(sd), n);
+                V3 refl = reflect(sd_unit, n);
                 nd = vadd(refl, smul(param, rs));
                 att = mk(u2f(mlo.x), u2f(mlo.y), u2f(mlo.z));
                 scattered = vdot(nd, n) > 0.f;
@@ -331,13 +334,13 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
                 if (dn > 0.f) {
                   outward = vneg(n);
                   ni_over_nt = param;
-                  cosine = param * dn / vlen(sd);
+                  cosine = param * dn / sd_len;
                 } else {
                   outward = n;
                   ni_over_nt = 1.0f / param;
-                  cosine = -dn / vlen(sd);
+                  cosine = -dn / sd_len;
                 }
-                V3 uv = vunit(sd);
+                V3 uv = sd_unit;
                 float dt = vdot(uv, outward);
                 float disc = 1.0f - ni_over_nt * ni_over_nt * (1.f - dt * dt);
                 bool refracted = disc > 0.f;

@@ -286,8 +286,8 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
   e = setup_lpt(s, cm, (uint64_t)grid * waves * POOL, stream);
   if (e != hipSuccess) return e;
   if (getenv("RTG_VERBOSE"))
-    fprintf(stderr, "[rtg] pool: grid %u x %d threads, %d WG/CU, lds %zu B (program staged: %d, rays in LDS: %d), %u chunk(s) of %u samples\n", grid,
-            bt, per_cu, lds, (int)use_lds, (int)ray_lds, cm.n_chunks, cm.chunk);
+    fprintf(stderr, "[rtg] pool: grid %u x %d threads, %d WG/CU, lds %zu B (program staged: %d, rays in LDS: %d), %u chunk(s) of %u samples, cost-ordered queue after %u chunk(s)\n", grid,
+            bt, per_cu, lds, (int)use_lds, (int)ray_lds, cm.n_chunks, cm.chunk, cm.lpt_samples / (cm.chunk ? cm.chunk : 1u));
   {
     size_t need = (size_t)grid * waves * POOL * POOL_FIELDS * sizeof(uint32_t);
     if (need > s->slots_bytes) {
@@ -413,8 +413,8 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
   e = grow((void**)&s->d_stack, &s->stack_bytes, (size_t)grid * waves * MAX_XFORM_DEPTH * 6 * 64 * sizeof(float));
   if (e != hipSuccess) return e;
   if (getenv("RTG_VERBOSE"))
-    fprintf(stderr, "[rtg] full pool: grid %u x %d threads, %d WG/CU, lds %zu B (program window: %u of %u records)\n", grid, bt,
-            per_cu, lds, window, s->n_prog);
+    fprintf(stderr, "[rtg] full pool: grid %u x %d threads, %d WG/CU, lds %zu B (program window: %u of %u records), cost-ordered queue after %u chunk(s)\n",
+            grid, bt, per_cu, lds, window, s->n_prog, cm.lpt_samples);
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(bt), lds, stream, s->dev, cam, d, d_out, (uint32_t)total_work, queue,
                      s->d_counters, s->full_tune, cm, s->d_slots, s->d_stack, window);
   e = hipGetLastError();

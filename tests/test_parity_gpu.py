@@ -263,6 +263,34 @@ def test_every_kernel_variant_and_schedule_gives_the_same_bits(pkg, gpu, oracle,
                          "%s shard %s" % (name, env))
 
 
+@pytest.mark.parametrize("env", [
+    {"RTG_LPT": "0"},                                                    # natural order throughout
+    {"RTG_LPT": "1", "RTG_LPT_PHASE1": "2", "RTG_LPT_DEEP": "0"},     # cost-ordered queue, block-major, every scatter counts
+    {"RTG_LPT": "2", "RTG_LPT_PHASE1": "2", "RTG_LPT_DEEP": "0"},     # ... class-major, chunk-major inside a class
+    {"RTG_LPT": "2", "RTG_LPT_PHASE1": "3", "RTG_LPT_DEEP": "2", "RTG_LPT_SHIFT": "3"},
+    {"RTG_LPT": "2", "RTG_LPT_PHASE1": "2", "RTG_RAY_LDS": "0"},      # slot rays in global memory
+])
+def test_cost_ordered_queue_never_changes_a_bit(pkg, gpu, oracle, env, monkeypatch):
+    """The cost-ordered work queue (rt_pool.h LptQueue) only engages on frames with >= 64 blocks and enough chunks;
+    RTG_LPT_PHASE1 forces it on at a size the oracle renders in a second.  Lean and full-feature kernel, one rank
+    and a shard."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)   # read by rtg_scene_create
+    for name, nx, ny, ns in (("book1", 176, 112, 12), ("cornell", 144, 128, 12), ("book2", 160, 112, 9)):
+        sg, cam_g, _, _, _ = build_case(pkg, gpu, name, nx, ny)
+        so, cam_o, _, _, _ = build_case(pkg, oracle, name, nx, ny)
+        img_o, st_o = so.par_cast(cam_o, nx, ny, ns, stats=True)
+        img_g, st_g = sg.par_cast(cam_g, nx, ny, ns, stats=True)
+        assert_bit_equal(img_g, img_o, "%s %s" % (name, env))
+        for k in ("samples", "aabb_tests", "prim_tests", "shaded_hits", "rays", "draws"):
+            assert st_g[k] == st_o[k], (name, env, k)
+        assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns), img_o, "%s %s (timed variant)" % (name, env))
+    sg, cam_g, _, _, _ = build_case(pkg, gpu, "book1", 352, 224)   # 308 tiles, 154 per rank
+    so, cam_o, _, _, _ = build_case(pkg, oracle, "book1", 352, 224)
+    assert_bit_equal(sg.par_cast(cam_g, 352, 224, 9, rank=1, nranks=2), so.par_cast(cam_o, 352, 224, 9, rank=1, nranks=2),
+                     "book1 shard %s" % (env,))
+
+
 def test_scene_reuse_across_sizes_and_sample_counts(pkg, gpu, oracle):
     """One scene handle, many calls: the library's scratch / path-slot buffers are grown lazily (a
     use-after-free here once produced a GPU memory fault when a second call needed a bigger scratch)."""
