@@ -291,6 +291,17 @@ def test_cost_ordered_queue_never_changes_a_bit(pkg, gpu, oracle, env, monkeypat
                      "book1 shard %s" % (env,))
 
 
+def test_tile_shapes_with_the_cost_ordered_queue(pkg, gpu, oracle, monkeypatch):
+    """Cost blocks are 256 consecutive work items: a whole 16x16 tile, or a quarter / sixth ... of a larger one."""
+    monkeypatch.setenv("RTG_LPT_PHASE1", "2")
+    for name, nx, ny, ns in (("book1", 352, 224, 9), ("book2", 224, 160, 9)):
+        sg, cam_g, _, _, _ = build_case(pkg, gpu, name, nx, ny)
+        so, cam_o, _, _, _ = build_case(pkg, oracle, name, nx, ny)
+        for kw in ({"tile_w": 32, "tile_h": 32}, {"tile_w": 48, "tile_h": 16, "rank": 2, "nranks": 3},
+                   {"tile_w": 16, "tile_h": 64, "rank": 0, "nranks": 2}):
+            assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns, **kw), so.par_cast(cam_o, nx, ny, ns, **kw), "%s %s" % (name, kw))
+
+
 def test_scene_reuse_across_sizes_and_sample_counts(pkg, gpu, oracle):
     """One scene handle, many calls: the library's scratch / path-slot buffers are grown lazily (a
     use-after-free here once produced a GPU memory fault when a second call needed a bigger scratch)."""
