@@ -2,24 +2,26 @@
 // path for the book-1 north-star workload.  Same arithmetic as rt_trace.h; the SCHEDULE is built for
 // CDNA4's 64-wide waves and 160 KB LDS:
 //
-//  * every wave owns a private pool of POOL = 128 path slots in LDS (2 per lane).  A slot holds a whole
-//    path state (ray, best hit, strength, accum, bounce/sample counters, pixel, running pixel sum).
+//  * every wave owns a private pool of POOL = 144 path slots.  A slot holds a whole path state: the ray
+//    (o, d) in LDS when the program leaves room (RAY_LDS), best hit, strength, bounce / sample counters
+//    and pixel as SoA rows in a per-wave region of global memory sized to stay in the L2s.
 //  * the wave's 64 lanes only TRAVERSE: a lane holds (o, d, 1/d, best, pc, current record) of one
 //    slot's ray in registers and walks the flat program (staged in LDS).  When its ray reaches END the
-//    lane writes (best, best_pc) back to the slot, pushes the slot on the wave's S-list and refills from
-//    the T-list -- lanes do not wait for each other's paths (wave-ballot compaction of the active-ray
-//    stream: ballot + mbcnt prefix ranks, no atomics because the lists are wave-private).
-//  * when 64 slots wait on the S-list the wave runs ONE full-width SHADE pass over them (hit record,
-//    Material::scatter, next sample's camera ray, next pixel from the global work counter), writes the
-//    new rays into the slots and pushes them on the T-list.  Shading therefore always runs 64 lanes
-//    wide instead of "whoever happened to finish".
+//    lane writes (best, best_pc) back to the slot, pushes the slot on the wave's S- or E-list and refills
+//    from the T-list -- lanes do not wait for each other's paths (wave-ballot compaction of the
+//    active-ray stream: ballot + mbcnt prefix ranks, no atomics because the lists are wave-private).
+//  * when 64 slots wait on the S-list the wave runs ONE full-width SCATTER pass over them (hit record,
+//    Material::scatter), when 64 wait on the E-list one END pass (book the sample, next work item,
+//    camera ray); both write the new rays into the slots and push them on the T-list.  Shading
+//    therefore always runs 64 lanes wide instead of "whoever happened to finish".
 //  * lanes that reach a SPHERE record park until enough of them wait, so the sqrt/divide sequence
 //    never runs for a handful of lanes; box steps run in a tight loop between schedule decisions.
-//  * workgroups are persistent (grid = CUs x resident workgroups); pixels come from one global
-//    counter with a wave-aggregated atomicAdd.
+//  * workgroups are persistent (one 16-wave workgroup per CU); work items -- one sample of one pixel --
+//    come from one global counter, 256 at a time, in an order that follows measured cost (LptQueue);
+//    a second kernel folds each pixel's samples in order.
 //
 // Scheduling never changes results: every (pixel, sample, event) has its own RNG stream and a pixel's
-// samples are folded in order inside its slot.
+// samples are folded in sample order.
 #pragma once
 #include "rt_persistent.h"
 
@@ -28,11 +30,11 @@ namespace rtg {
 #ifndef RT_POOL_SLOTS
 #define RT_POOL_SLOTS 144  // 8 global dwords x 144 slots x 4 096 waves = 2.4 MB per XCD: the slot rows stay in the 4 MB L2s
 #endif
-constexpr uint32_t POOL = RT_POOL_SLOTS;           // path slots per wave: 64 in lanes + 128 waiting, so one wait list always holds >= 64
+constexpr uint32_t POOL = RT_POOL_SLOTS;           // path slots per wave: 64 in lanes + 80 waiting (a wait list reaches 64 while the lanes drain)
 constexpr uint32_t POOL_FIELDS = 17;     // dwords per slot (SoA: field f of slot j at [f * POOL + j]); 14 in chunk mode
 constexpr uint32_t WORK_BLOCK = 256;     // work items a wave reserves per global atomic (2048 cost 20 % on C2: ~6 blocks per wave = a coarse tail)
 constexpr uint32_t SLOT_NEED_PIXEL = 0xfffffffeu;  // best_pc marker: slot holds no ray yet
-constexpr uint32_t SLOT_ENDED = 0xfffffffdu;       // best_pc marker: path ended in a SCATTER pass, colour parked in accum
+constexpr uint32_t SLOT_ENDED = 0xfffffffdu;       // best_pc marker: path ended in a SCATTER pass (its colour is accum = +0)
 
 enum PoolField : uint32_t {
   PF_O = 0, PF_D = 3, PF_BEST = 6, PF_BEST_PC = 7, PF_STRENGTH = 8, PF_BOUNCES = 11, PF_SAMPLE = 12, PF_XY = 13, PF_COL = 14,
