@@ -866,6 +866,14 @@ int rtg_par_cast_device(rtg_scene* s, const rtg_camera* camera, const rtg_params
     unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (count) HIP_TRY(hipMemcpy(h, s->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     stats->aabb_tests = h[0], stats->prim_tests = h[1], stats->shaded_hits = h[2], stats->rays = h[3], stats->draws = h[4];
+    if (count && getenv("RTG_VERBOSE") && s->lpt_desc.n_blocks && s->d_lpt) {  // cost classes of the last frame (class 0 = deepest)
+      std::vector<uint32_t> ctl(LPT_CTL);
+      HIP_TRY(hipMemcpy(ctl.data(), s->lpt_desc.ctl, LPT_CTL * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      std::string line;
+      for (uint32_t c = 0; c < LPT_CLASSES; c++)
+        if (ctl[c]) line += " " + std::to_string(c) + ":" + std::to_string(ctl[c]);
+      fprintf(stderr, "[rtg] cost-ordered queue: %u of %u blocks filed, class:blocks%s\n", ctl[LPT_CLASSES], s->lpt_desc.n_blocks, line.c_str());
+    }
     if (count && getenv("RTG_VERBOSE")) {
       unsigned long long q[24];
       HIP_TRY(hipMemcpy(q, s->d_counters + 8, sizeof(q), hipMemcpyDeviceToHost));
