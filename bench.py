@@ -2,9 +2,12 @@
 """bench.py -- Msamples/s of the path-tracing hot path on MI355X (BASELINE.json metric).
 
 A "step" = one full par_cast of the workload into a framebuffer resident in HBM.
-  N = 1 : book-1 random-spheres, 1200x800, 50 spp (BASELINE.json configs[1]).
-  N > 1 : the same frame at 50*N spp, pixel tiles sharded over the N ranks (weak scaling: per-GPU
-          samples fixed), then ONE RCCL reduce(sum) of the float3 framebuffer to rank 0.
+  N = 1 : book-1 random-spheres, 1200x800, 50 spp (BASELINE.json configs[1], C2).
+  N > 1 : the FIXED frame of configs[2] (C3): book-1 1200x800 at 500 spp, its 16x16 pixel tiles sharded over the N
+          ranks (tile % N == rank), then ONE RCCL reduce(sum) of the float3 framebuffer to rank 0 -- strong
+          scaling, as north_star states it ("1200x800x500spp reported at 1/2/4/8 MI355X").
+          `--workload book2`: N = 1 renders configs[3] (C4, 800x800x1000), N > 1 the fixed frame of configs[4]
+          (C5, 800x800x5000).  `--scaling weak` keeps the per-GPU samples fixed instead (spp = N x the N = 1 spp).
 Launch for N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
 Prints ONE JSON line on rank 0.
 """
@@ -23,6 +26,16 @@ import __graft_entry__ as graft  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def usable_cores():
     """Threads this process may really run: affinity mask capped by the cgroup CPU quota
     (the GPU box shows 256 hardware threads but its container is quota-limited)."""
@@ -37,12 +50,13 @@ def usable_cores():
 
 
 WORKLOADS = {
-    # name: (scene builder(pkg, b, nx, ny) -> (world, camera, exposure), nx, ny, spp per GPU, description)
-    "book1": (lambda pkg, b, nx, ny: pkg.scenes.random_scene(b, nx, ny), 1200, 800, 50,
+    # name: (scene builder(pkg, b, nx, ny) -> (world, camera, exposure), nx, ny, spp at N = 1, spp of the fixed frame
+    #        sharded at N > 1, description)
+    "book1": (lambda pkg, b, nx, ny: pkg.scenes.random_scene(b, nx, ny), 1200, 800, 50, 500,
               "SmallRng(0xDEADBEEF) book-1 random spheres under bvh::from_scene + sky-dome emitter (SURVEY.md 8d)"),
-    "book2": (lambda pkg, b, nx, ny: pkg.scenes.book_final_scene(b, nx, ny, pkg.small_rng.SmallRng(0xDEADBEEF)), 800, 800, 1000,
+    "book2": (lambda pkg, b, nx, ny: pkg.scenes.book_final_scene(b, nx, ny, pkg.small_rng.SmallRng(0xDEADBEEF)), 800, 800, 1000, 5000,
               "book_final_scene (src/main.rs:161-319), list world (USE_BVH = false), SmallRng(0xDEADBEEF) construction"),
-    "cornell": (lambda pkg, b, nx, ny: pkg.scenes.cornell_box_scene(b, nx, ny), 300, 300, 100,
+    "cornell": (lambda pkg, b, nx, ny: pkg.scenes.cornell_box_scene(b, nx, ny), 300, 300, 100, 100,
                 "cornell_box_scene (src/main.rs:11-30): Cornell box + two prisms, list world"),
 }
 
@@ -64,8 +78,12 @@ def cpu_baseline(pkg, build_scene, nx, ny, target_seconds=12.0, max_spp=1000):
     scene.par_cast(cam, nx, ny, spp, threads=cores)
     dt = time.perf_counter() - t0
     return {"value": nx * ny * spp / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model(),
             "sample": "%dx%d at %d spp (same scene and seed), oracle par_cast on %d threads, %.1f s"
-                      % (nx, ny, spp, cores, dt)}
+                      % (nx, ny, spp, cores, dt),
+            "note": "kind 'port': the Rust + Rayon reference cannot be built here or on the GPU box (no rustc / cargo, "
+                    "rand / rayon not vendored, no network); this is the C++ oracle's row-parallel par_cast "
+                    "(same row granularity as lib.rs:326-330) on the cores the cgroup quota allows"}
 
 
 def main():
@@ -80,7 +98,10 @@ def main():
                          "default); 'sah' = the surface-area-heuristic builder (SURVEY.md 8 f2: same image, fewer Aabb tests)")
     ap.add_argument("--nx", type=int, default=0)
     ap.add_argument("--ny", type=int, default=0)
-    ap.add_argument("--spp", type=int, default=0, help="samples per pixel (default: the workload's spp * gpus)")
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel (default: see --scaling)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: 'strong' (default) shards the workload's FIXED multi-GPU frame (book1: 500 spp = C3, "
+                         "book2: 5000 spp = C5); 'weak' renders N x the N = 1 spp (per-GPU samples fixed)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xDEADBEEF)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true",
@@ -112,12 +133,17 @@ def main():
 
     pkg = graft.load_package()
     gpu = pkg.load()
-    build_scene, wnx, wny, wspp, wdesc = WORKLOADS[args.workload]
+    build_scene, wnx, wny, wspp, wspp_multi, wdesc = WORKLOADS[args.workload]
     if args.workload == "book1" and args.bvh == "sah":
         build_scene = lambda pkg, b, nx, ny: pkg.scenes.random_scene(b, nx, ny, use_bvh="sah")  # noqa: E731
         wdesc = wdesc.replace("bvh::from_scene", "a SAH-built Bvh (non-reference tree shape)")
     nx, ny = args.nx or wnx, args.ny or wny
-    spp = args.spp or wspp * world
+    if args.spp:
+        spp = args.spp
+    elif world == 1:
+        spp = wspp
+    else:
+        spp = wspp_multi if args.scaling == "strong" else wspp * world
 
     b = gpu.builder()
     objs, cam, _ = build_scene(pkg, b, nx, ny)
@@ -125,29 +151,23 @@ def main():
     info = scene.info()
     info_lean = args.workload == "book1"
 
-    fb = torch.zeros((ny, nx, 3), dtype=torch.float32, device=dev)
+    from rtiow_rust_amd import parallel   # the ONE sharding implementation (also what tests/test_dist_cpu.py drives)
+    frame = parallel.ShardedFrame(nx, ny, dev, via_host=(backend != "nccl"))
+    fb = frame.fb
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def step(flags=0):
-        p = pkg.make_params(nx, ny, spp, seed=args.seed, rank=rank, nranks=world, flags=flags)
-        st = scene.par_cast_device(cam, p, ctypes.c_void_p(fb.data_ptr()), stream, want_stats=True)
-        if world > 1:
-            if backend == "nccl":
-                dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)   # ONE collective: float3 framebuffer over RCCL/xGMI
-            else:
-                host = fb.cpu()
-                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
-                fb.copy_(host)
-        return st
+        def render_shard(fb_, rank_, world_):
+            p = pkg.make_params(nx, ny, spp, seed=args.seed, rank=rank_, nranks=world_, flags=flags)
+            return scene.par_cast_device(cam, p, ctypes.c_void_p(fb_.data_ptr()), stream, want_stats=True)
+        return frame.render(render_shard)   # zero, this rank's tiles, ONE reduce(sum) to rank 0
 
     # counting pass (untimed): the instrumented kernel gives N/P/H for the algorithmic byte model
-    fb.zero_()
     cst = step(flags=pkg.capi.FLAG_COUNTERS)
     px_rank = cst["samples"] // spp
     algo_bytes = 32 * cst["aabb_tests"] + 32 * cst["prim_tests"] + 32 * cst["shaded_hits"] + 12 * px_rank
 
     for _ in range(args.warmup):
-        fb.zero_()
         step()
 
     def sync():
@@ -157,7 +177,6 @@ def main():
 
     verified = None
     if args.verify:
-        fb.zero_()
         step()
         sync()
         if rank == 0:
@@ -170,8 +189,6 @@ def main():
     t0 = time.perf_counter()
     kernel_ms = []
     for _ in range(args.steps):
-        if world > 1:
-            fb.zero_()
         kernel_ms.append(step()["kernel_ms"])
     sync()
     elapsed = time.perf_counter() - t0
@@ -184,18 +201,40 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         total_samples = nx * ny * spp
         avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
-        achieved = algo_bytes / (avg_kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if world == 1 and os.path.exists(tpath):
-            # measured separately (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command,
-            # tools/summarize_pmc.py); counters cannot be read from inside the process
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("workload") == "%s_%dx%dx%d" % (args.workload, nx, ny, spp):
-                    traffic = tj["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
+        # ---- roofline of the dominant kernel ------------------------------------------------------------------
+        # Binding resource: VALU issue (the scene is LDS-resident, path state LDS / L2-resident: neither HBM nor MFMA
+        # can bound this kernel).  achieved = SQ_INSTS_VALU per launch (rocprofv3 PMC pass of THIS command, committed
+        # under profiles/, scaled per sample when the spp differs) / the kernel time measured LIVE here with HIP
+        # events on the launch stream; peak = 256 CUs x 4 SIMDs x shader clock / issue cycles per wave64 instruction.
+        # tools/roofline.py recomputes the same object from profiles/<tag>/pmc_summary.json + kernel_stats.csv.
+        from rtiow_rust_amd import roofline as rl
+        kernel_name = ("rtg::render_lean_pool" if info_lean else "rtg::render_full_pool")
+        kernel_s = avg_kernel_ms * 1e-3
+        rank_samples = px_rank * spp
+        pmc, pmc_path = rl.find_profile(ROOT, args.workload if args.bvh == "reference" else args.workload + "_" + args.bvh)
+        if pmc is not None:
+            roof = rl.valu_roofline(pmc, kernel_s, samples=rank_samples)
+            roof["pmc_source"] = pmc_path
+        else:   # no counter profile for this workload: the contract's keys with the unmeasured ones null
+            roof = {"bound": "valu", "achieved": None, "peak": rl.N_CUS * rl.SIMDS_PER_CU * rl.NOMINAL_CLOCK_HZ / rl.ISSUE_CYCLES / 1e9,
+                    "unit": "G wave-instructions/s", "frac": None, "traffic": None}
+        roof.update({
+            "kernel": kernel_name + " (+ rtg::fold_samples_kernel, ~1%): HIP events around both on the launch stream",
+            "kernel_ms_avg": avg_kernel_ms,
+            # SURVEY.md 8(d)'s model figure, kept as a LABELLED secondary: these bytes are served by the LDS image of
+            # the scene, not by HBM, so their rate may exceed the HBM peak and is no fraction of anything
+            "algorithmic": {"bytes_per_launch": algo_bytes, "rate_GBps": algo_bytes / kernel_s / 1e9, "lds_served": True,
+                            "formula": "32*aabb_tests + 32*prim_tests + 32*shaded_hits + 12*pixels (SURVEY.md 8d)"},
+            "counters_per_launch": {k: cst[k] for k in ("aabb_tests", "prim_tests", "shaded_hits", "rays", "draws")},
+        })
+        if world == 1:
+            shard_txt = "none"
+        elif args.scaling == "strong" or args.spp:
+            shard_txt = ("the FIXED %dx%dx%d frame, interleaved 16x16 pixel tiles (tile %% %d == rank): strong scaling; ONE RCCL "
+                         "reduce(sum) of the float3 framebuffer to rank 0 per frame" % (nx, ny, spp, world))
+        else:
+            shard_txt = ("interleaved 16x16 pixel tiles (tile %% %d == rank), spp = %d*N: weak scaling; ONE RCCL reduce(sum) "
+                         "of the float3 framebuffer to rank 0 per frame" % (world, wspp))
         line = {
             "metric": "Msamples/s (pixels*spp/s), %s %dx%d" % (
                 {"book1": "book-1 random-spheres", "book2": "book-2 final scene", "cornell": "Cornell box"}[args.workload], nx, ny),
@@ -203,27 +242,21 @@ def main():
             "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True,
+            "scaling": "weak" if (world > 1 and args.scaling == "weak" and not args.spp) else "strong",
+            "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": "%s_%dx%dx%dspp" % ({"book1": "book1_random_spheres", "book2": "book2_final_scene",
                                                  "cornell": "cornell_box_with_boxes"}[args.workload], nx, ny, spp),
+                "baseline_config": {("book1", 50): "configs[1]", ("book1", 500): "configs[2]", ("book2", 1000): "configs[3]",
+                                    ("book2", 5000): "configs[4]", ("cornell", 100): "configs[0]"}.get((args.workload, spp)),
                 "scene": "%s, %d flat-program instructions, %d materials, %d B in HBM"
                          % (wdesc, info["instructions"], info["materials"], info["hbm_bytes"]),
                 "max_bounces": 50, "seed": hex(args.seed),
-                "sharding": "none" if world == 1 else
-                            "interleaved 16x16 pixel tiles (tile %% %d == rank), spp = %d*N; RCCL reduce(sum) of the "
-                            "float3 framebuffer to rank 0" % (world, wspp),
+                "sharding": shard_txt,
             },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": ("rtg::render_lean_pool" if info_lean else "rtg::render_full_pool") +
-                          " (+ rtg::fold_samples_kernel, <1%): HIP events around both on the launch stream",
-                "kernel_ms_avg": avg_kernel_ms,
-                "algorithmic_bytes_per_launch": algo_bytes,
-                "counters_per_launch": {k: cst[k] for k in ("aabb_tests", "prim_tests", "shaded_hits", "rays", "draws")},
-            },
+            "roofline": roof,
         }
         if verified is not None:
             line["verified_bit_exact_vs_unsharded"] = verified

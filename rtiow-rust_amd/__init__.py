@@ -28,5 +28,7 @@ def load():
     """Load librtiow_gpu.so (the HIP product).  Fails loudly when it has not been built."""
     global _backend
     if _backend is None:
-        _backend = Backend(LIB_PATH, "rtg_")
+        # RTIOW_GPU_LIB: measurement hook (tools/sweep*.sh) -- another BUILD of the same HIP library, e.g. one compiled
+        # with different -DRT_* experiment defines; never anything but librtiow_gpu
+        _backend = Backend(os.environ.get("RTIOW_GPU_LIB", LIB_PATH), "rtg_")
     return _backend

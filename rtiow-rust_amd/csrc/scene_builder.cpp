@@ -421,22 +421,51 @@ void SceneBuilder::flatten(const uint32_t* world, size_t n, FlatScene* out) cons
   }
   close_run(out->lo.size());
   push(out, 0, 0, 0, 0, 0, 0, 0, OP_END);
+  // Albedo range of every scattering material -- decides whether the pool kernels' "accum is +0" argument holds
+  // (rt_pool.h PoolField): walks the WHOLE texture tree (a checker's children, recursively; texture.rs:12-21), any
+  // reachable Perlin texture is "bright" (turb <= 2 sqrt(3) x the longest table vector, perlin.rs:31-75), and a Perlin
+  // table with vectors longer than unit length (or NaN) has no bound at all.
+  float perlin_len2 = 0.f;
+  bool perlin_bad = false;
+  if (has_perlin)
+    for (int i = 0; i < 256; i++) {
+      const float* v = &perlin_vecs[4 * i];
+      const float l2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
+      if (!(l2 <= 1.0002f)) perlin_bad = true;
+      if (l2 > perlin_len2) perlin_len2 = l2;
+    }
+  auto range_of_constant = [&](const float c[3]) {
+    for (int i = 0; i < 3; i++) {
+      if (!(c[i] >= 0.f && c[i] <= 4.f)) out->features |= FEAT_WIDE_ALBEDO;
+      else if (c[i] > 1.f) out->features |= FEAT_BRIGHT_ALBEDO;
+    }
+  };
+  std::vector<uint32_t> todo;
+  auto range_of_texture = [&](uint32_t root) {
+    todo.assign(1, root);
+    while (!todo.empty()) {
+      const uint32_t id = todo.back();
+      todo.pop_back();
+      const HostTexture& t = textures[id];
+      if (t.kind == TEX_CONSTANT) range_of_constant(t.rgb);
+      else if (t.kind == TEX_PERLIN) out->features |= perlin_bad ? FEAT_WIDE_ALBEDO : FEAT_BRIGHT_ALBEDO;
+      else todo.push_back(t.t0), todo.push_back(t.t1);  // checker: children were created earlier (ids < id): no cycles
+    }
+  };
   for (const HostMaterial& m : materials) {
     float c[3] = {m.albedo[0], m.albedo[1], m.albedo[2]};
     uint32_t texkind = TEX_CONSTANT, tex = 0;
+    const bool scatters_with_albedo = m.kind != MAT_DIFFUSE_LIGHT && m.kind != MAT_DIELECTRIC;
     if (m.tex != kNone) {
       const HostTexture& t = textures[m.tex];
       texkind = t.kind;
       tex = m.tex;
       if (t.kind == TEX_CONSTANT) c[0] = t.rgb[0], c[1] = t.rgb[1], c[2] = t.rgb[2];
       else out->features |= FEAT_TEXTURE;
-      if (t.kind == TEX_PERLIN) out->features |= FEAT_BRIGHT_ALBEDO;
+      if (scatters_with_albedo) range_of_texture(m.tex);
+    } else if (scatters_with_albedo) {
+      range_of_constant(c);
     }
-    if (m.kind != MAT_DIFFUSE_LIGHT && m.kind != MAT_DIELECTRIC)
-      for (float a : c) {
-        if (!(a >= 0.f && a <= 4.f)) out->features |= FEAT_WIDE_ALBEDO;
-        else if (a > 1.f) out->features |= FEAT_BRIGHT_ALBEDO;
-      }
     out->mat.push_back(Packet{{fbits(c[0]), fbits(c[1]), fbits(c[2]), fbits(m.param)}});
     out->mat.push_back(Packet{{tex, 0, 0, m.kind | (texkind << 8)}});
   }

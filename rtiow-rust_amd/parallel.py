@@ -1,25 +1,59 @@
 """Multi-GPU sharding of par_cast: one process per GPU, pixels (not samples) partitioned.
 
 The per-pixel mean is an ORDERED left fold over samples (lib.rs:365-374), so splitting samples across
-GPUs would change the f32 addition order; pixels are independent, so the image is cut into tiles and
+GPUs would change the f32 addition order; pixels are independent, so the image is cut into 16x16 tiles and
 rank r renders the tiles with tile_index % world == r (rtg_params.rank/nranks).  Every rank writes its
 pixels into a zero-filled full-frame buffer; ONE collective -- reduce(sum) to rank 0 over RCCL/xGMI --
 assembles the frame.  x + 0 is exact, so the result is bit-identical to the single-GPU frame.
+
+`ShardedFrame` is the ONE implementation of that: bench.py's N > 1 leg drives it over RCCL ("nccl"), the CPU
+test (tests/test_dist_cpu.py) over gloo with the oracle as the shard renderer.  The single-process twin inside the
+library is rtg_par_cast_multi (include/rtiow_gpu.h).
 """
 import torch
 import torch.distributed as dist
 
 
-def reduce_framebuffer(fb, dst=0):
-    """fb: full-frame float32 tensor, zero outside this rank's tiles.  In-place reduce to `dst`."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM)
-    return fb
+def world_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
 
 
-def render_sharded(render_shard, nx, ny, rank, world, device):
-    """render_shard(fb, rank, world) must fill this rank's tiles of fb ([ny, nx, 3] float32 on `device`).
-    Returns the assembled frame on rank 0 (other ranks: their partial frame)."""
-    fb = torch.zeros((ny, nx, 3), dtype=torch.float32, device=device)
-    render_shard(fb, rank, world)
-    return reduce_framebuffer(fb)
+class ShardedFrame:
+    """A full-frame float3 buffer on `device` that this rank fills with ITS tiles and rank 0 receives whole.
+
+    render_shard(fb, rank, world) must write this rank's pixels of fb ([ny, nx, 3] float32) and leave the others
+    alone; `via_host` reduces through host memory (gloo cannot reduce device tensors of a GPU it shares with
+    another rank: the one-GPU test hook of bench.py)."""
+
+    def __init__(self, nx, ny, device, via_host=False):
+        self.rank, self.world = world_info()
+        self.fb = torch.zeros((ny, nx, 3), dtype=torch.float32, device=device)
+        self.via_host = via_host
+
+    def render(self, render_shard, dst=0):
+        """One frame: zero (other ranks' pixels must contribute +0), render this rank's tiles, ONE reduce(sum)."""
+        if self.world > 1:
+            self.fb.zero_()
+        out = render_shard(self.fb, self.rank, self.world)
+        self.reduce(dst)
+        return out
+
+    def reduce(self, dst=0):
+        if self.world <= 1:
+            return self.fb
+        if self.via_host:
+            host = self.fb.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+            self.fb.copy_(host)
+        else:
+            dist.reduce(self.fb, dst=dst, op=dist.ReduceOp.SUM)   # the float3 framebuffer over RCCL / xGMI
+        return self.fb
+
+
+def render_sharded(render_shard, nx, ny, device, via_host=False):
+    """Convenience: one sharded frame; returns the assembled frame on rank 0 (other ranks: their partial sums)."""
+    frame = ShardedFrame(nx, ny, device, via_host=via_host)
+    frame.render(render_shard)
+    return frame.fb

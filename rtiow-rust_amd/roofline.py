@@ -1,0 +1,94 @@
+"""Roofline arithmetic for the render kernels -- shared by bench.py (live kernel time) and tools/roofline.py
+(recomputes the same numbers from the committed profiles/<tag>/pmc_summary.json + kernel_stats.csv).
+
+The path tracer's scene lives in LDS and its path state in LDS / L2, so neither HBM nor MFMA bounds it (SURVEY.md
+8d "reality check"); the binding resource is VALU ISSUE: every SIMD of a CU can start one wave64 VALU instruction
+every `issue_cycles` = 2 shader cycles (MI355X_MICROARCH.md "Wave scheduling"; tools/ubench/issue_rate.hip, timed with
+s_memtime inside the kernel, reaches 2.17 cycles per instruction on the box step's own instruction mix from 2 waves
+per SIMD on, 2.7 on a single repeated add / mul / fma, ~4.5 on max3 / cmp / v_pk_* / integer multiplies).  Hence
+
+    peak      = CUs x 4 SIMDs x 2.4 GHz (max clock) / issue_cycles   [wave-instructions / s]
+    achieved  = SQ_INSTS_VALU per launch / kernel seconds             [wave-instructions / s]
+    frac      = achieved / peak                      -- how busy the VALU issue ports are
+    lane_util = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)    -- how many of the 64 lanes do work
+    frac x lane_util = fraction of the f32 lane peak doing useful work (divergence included)
+
+and next to it the measured HBM side (rocprofv3 FETCH_SIZE / WRITE_SIZE, corrected as the guide prescribes) against
+the 8 TB/s peak, and the LDS array duty (SQ_LDS_IDX_ACTIVE / CU-cycles).  The SURVEY 8(d) "algorithmic bytes" figure
+stays as a labelled model number: those bytes are served by LDS, not by HBM.
+"""
+import json
+import os
+
+N_CUS = 256
+SIMDS_PER_CU = 4
+NOMINAL_CLOCK_HZ = 2.4e9   # MI355X_MICROARCH.md chip table
+ISSUE_CYCLES = 2.0         # shader cycles per wave64 VALU instruction per SIMD (guide; issue_rate.hip confirms/corrects)
+HBM_PEAK_GBS = 8000.0
+XCDS = 8
+
+
+def load_pmc(path):
+    with open(path) as f:
+        return json.load(f)
+
+
+def shader_clock_hz(pmc, kernel_s_profiled=None):
+    """GRBM_GUI_ACTIVE is summed over the 8 XCDs: cycles per XCD / kernel seconds = the clock the chip really ran at."""
+    c = pmc.get("counters_avg_per_launch", {})
+    if kernel_s_profiled and c.get("GRBM_GUI_ACTIVE"):
+        return c["GRBM_GUI_ACTIVE"] / XCDS / kernel_s_profiled
+    return None
+
+
+def valu_roofline(pmc, kernel_s, samples=None, clock_hz=None, issue_cycles=None):
+    """pmc: a pmc_summary.json dict; kernel_s: seconds per launch (live HIP events or kernel_stats.csv);
+    samples: samples rendered by the timed launch when it differs from the profiled one (counts scale per sample)."""
+    c = pmc["counters_avg_per_launch"]
+    scale = 1.0
+    if samples is not None and pmc.get("samples_per_launch"):
+        scale = samples / float(pmc["samples_per_launch"])
+    insts = c["SQ_INSTS_VALU"] * scale
+    clock = clock_hz or NOMINAL_CLOCK_HZ   # the chip's maximum clock: the profiled launch itself ran at pmc["shader_clock_hz"]
+    cyc = issue_cycles or pmc.get("issue_cycles") or ISSUE_CYCLES
+    peak = N_CUS * SIMDS_PER_CU * clock / cyc
+    achieved = insts / kernel_s
+    lane_util = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]) if c.get("SQ_ACTIVE_INST_VALU") else None
+    out = {
+        "bound": "valu",
+        "achieved": achieved / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s",
+        "frac": achieved / peak,
+        "valu_wave_instructions_per_launch": insts,
+        "lane_utilization": lane_util,
+        "frac_of_f32_lane_peak": (achieved / peak) * lane_util if lane_util else None,
+        "shader_clock_hz": clock, "shader_clock_measured_hz": pmc.get("shader_clock_hz"),
+        "issue_cycles_per_wave_instruction": cyc,
+    }
+    if c.get("SQ_LDS_IDX_ACTIVE") and c.get("SQ_BUSY_CU_CYCLES"):
+        # LDS-array cycles over the cycles CUs were busy (both summed over the chip)
+        out["lds_array_duty"] = c["SQ_LDS_IDX_ACTIVE"] / c["SQ_BUSY_CU_CYCLES"]
+    if "hbm_bytes_per_launch" in pmc:
+        traffic = pmc["hbm_bytes_per_launch"] * scale
+        out["traffic"] = traffic
+        out["hbm"] = {"achieved": traffic / kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": traffic / kernel_s / 1e9 / HBM_PEAK_GBS,
+                      "fetch_bytes": pmc.get("fetch_bytes_corrected", 0) * scale, "write_bytes": pmc.get("write_bytes", 0) * scale}
+    else:
+        out["traffic"] = None
+    return out
+
+
+def find_profile(root, workload_key):
+    """profiles/current.json maps a workload key ("book1", "book2", "cornell") to the pmc_summary.json of the kernel
+    build that is checked in (written by tools/collect_profiles.sh)."""
+    idx = os.path.join(root, "profiles", "current.json")
+    if not os.path.exists(idx):
+        return None, None
+    try:
+        rel = json.load(open(idx)).get(workload_key)
+        if not rel:
+            return None, None
+        path = os.path.join(root, rel)
+        return load_pmc(path), rel
+    except Exception:
+        return None, None

@@ -115,6 +115,38 @@ def test_flat_program_of_cornell_and_book2(pkg):
     assert not (words[med, 7] & (1 << 12)).any()        # list world: not under a Bvh
 
 
+def test_albedo_range_flags_walk_the_texture_tree(pkg):
+    """The pool kernels keep no accum field; the flattener must prove every reachable albedo stays in range -- through
+    checker children (texture.rs:12-21) and Perlin tables (perlin.rs), not only for top-level constants."""
+    be = pkg.load()
+    S = pkg.scenes
+    WIDE, BRIGHT = 32, 64
+
+    def feat(make):
+        b = be.builder()
+        return b.flatten([b.sphere(1.0, make(b))])[1] & (WIDE | BRIGHT)
+
+    assert feat(lambda b: b.lambertian(b.constant(S.vfrom(0.5)))) == 0
+    assert feat(lambda b: b.lambertian(b.constant(S.vfrom(100.0)))) == WIDE
+    assert feat(lambda b: b.lambertian(b.checker(b.constant(S.vfrom(0.2)), b.constant(S.vfrom(0.9))))) == 0
+    assert feat(lambda b: b.lambertian(b.checker(b.constant(S.vfrom(100.0)), b.constant(S.vfrom(float("nan")))))) == WIDE
+    assert feat(lambda b: b.lambertian(b.checker(b.constant(S.vfrom(7.0)), b.constant(S.vfrom(-0.5))))) == WIDE
+    assert feat(lambda b: b.isotropic(b.checker(b.constant(S.vfrom(0.5)), b.checker(b.constant(S.vfrom(0.1)), b.constant(S.vfrom(1.5)))))) == BRIGHT
+    assert feat(lambda b: b.diffuse_light(b.checker(b.constant(S.vfrom(100.0)), b.constant(S.vfrom(-3.0))), 15.0)) == 0  # emission: no albedo
+    rs = np.random.RandomState(1)
+    v = rs.standard_normal((256, 3)).astype(np.float32)
+    unit = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    perm = [rs.permutation(256).astype(np.uint8) for _ in range(3)]
+
+    def with_tables(vecs):
+        def make(b):
+            b.set_perlin_tables(vecs, *perm)
+            return b.lambertian(b.checker(b.constant(S.vfrom(0.5)), b.perlin(4.0)))   # Perlin as a CHILD of a checker
+        return make
+    assert feat(with_tables(unit)) == BRIGHT
+    assert feat(with_tables(unit * np.float32(3.0))) == WIDE       # no turbulence bound for over-long gradient vectors
+
+
 def test_reference_error_behaviour(pkg):
     be = pkg.load()
     S = pkg.scenes

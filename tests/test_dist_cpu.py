@@ -23,7 +23,7 @@ scene, cam, nx, ny, ns = build_case(pkg, ora, "book1", 64, 48)
 def render_shard(fb, rank, world):
     part = scene.par_cast(cam, nx, ny, ns, rank=rank, nranks=world, threads=2)
     fb.copy_(torch.from_numpy(part))
-frame = parallel.render_sharded(render_shard, nx, ny, rank, world, torch.device("cpu"))
+frame = parallel.render_sharded(render_shard, nx, ny, torch.device("cpu"))
 if rank == 0:
     np.save(sys.argv[1], frame.numpy())
 dist.barrier(); dist.destroy_process_group()
