@@ -151,9 +151,23 @@ int rtg_par_cast(rtg_scene* s, const rtg_camera* camera, const rtg_params* param
                  rtg_stats* stats_or_null);
 /* Same, but out_rgb is DEVICE memory on the scene's device and the kernel is enqueued on
  * `hip_stream` (a hipStream_t, NULL = default stream).  Asynchronous unless stats are requested
- * (stats need the kernel to finish). */
+ * (stats need the kernel to finish).  A scene handle allows ONE frame in flight: it owns the launch's work-queue
+ * counter and scratch buffers and may re-grow them on the next call -- wait for the previous frame of the same handle
+ * (or use a second handle) before calling again. */
 int rtg_par_cast_device(rtg_scene* s, const rtg_camera* camera, const rtg_params* params,
                         float* d_out_rgb, void* hip_stream, rtg_stats* stats_or_null);
+
+/* Single-process multi-GPU par_cast (SURVEY.md 8b `rtg_render_multi`; reference seam lib.rs:363-376): `scenes[i]` is
+ * the SAME world flattened onto device i's HBM (rtg_scene_create with that device index; the scene is small and
+ * read-only, so it is replicated).  Scene i renders the 16x16 pixel tiles with tile_index % n_scenes == i into a
+ * zero-filled full frame on its device -- pixels, not samples, are sharded, so every pixel keeps the reference's
+ * ordered sample fold -- then ONE collective, ncclReduce(sum) of the float3 framebuffer to the first device over
+ * RCCL / xGMI (librccl is dlopen()ed on first use with > 1 distinct device), assembles the frame: x + 0 is exact, the
+ * result is bit-identical to rtg_par_cast on one GPU.  Scenes that share a device are summed on that device first.
+ * params->rank / nranks must be 0 / 0-or-1 (the call shards by itself).  out_rgb: caller-owned HOST memory.
+ * stats: kernel_ms = the slowest shard, counters summed over the shards.  Synchronous. */
+int rtg_par_cast_multi(rtg_scene* const* scenes, int n_scenes, const rtg_camera* camera,
+                       const rtg_params* params, float* out_rgb, rtg_stats* stats_or_null);
 
 /* ---- output stage -------------------------------------------------------------------------- */
 /* print_ppm's per-channel quantisation (lib.rs:348-356): sqrt gamma, `(255.99 * x) as i32` (saturating,

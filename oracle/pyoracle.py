@@ -45,6 +45,8 @@ def load(pkg):
             f = self._fn
             f("par_cast", C.c_int, [C.c_void_p, C.POINTER(capi.Camera), C.POINTER(capi.Params), capi.c_f32p,
                                     C.POINTER(capi.Stats), C.c_int])
+            f("par_cast_multi", C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(capi.Camera), C.POINTER(capi.Params),
+                                          capi.c_f32p, C.POINTER(capi.Stats)])
             f("cast", C.c_int, [C.c_void_p, C.POINTER(capi.Camera), C.c_uint32, C.c_uint32, C.c_uint32,
                                 C.c_uint32, C.c_uint64, capi.c_f32p])
 

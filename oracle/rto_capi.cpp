@@ -361,6 +361,10 @@ int rto_par_cast(rto_scene* s, const rto_camera* camera, const rto_params* param
   if (!s || !camera || !params || !out_rgb) return fail(-1, "null argument");
   if (!(camera->exposure_start < camera->exposure_end))
     return fail(-4, "Uniform::sample_single called with low >= high");  // camera.rs:55
+  if (!std::isfinite(camera->exposure_start) || !std::isfinite(camera->exposure_end))  // rand 0.6.5: "non-finite boundaries"
+    return fail(-4, "Uniform::sample_single called with non-finite boundaries");
+  if (!std::isfinite(camera->exposure_end - camera->exposure_start))  // rand would shrink the scale; not restated (endless retry otherwise)
+    return fail(-4, "exposure range wider than f32::MAX is not supported");
   const rto_params p = *params;
   Camera cam = to_camera(camera);
   int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
@@ -398,6 +402,35 @@ int rto_par_cast(rto_scene* s, const rto_camera* camera, const rto_params* param
     stats->shaded_hits = total.shaded_hits;
     stats->rays = total.rays;
     stats->draws = total.draws;
+  }
+  return 0;
+}
+
+// Mirror of rtg_par_cast_multi (same signature): every "device" renders its tile shard into a zero-filled frame and
+// the frames are summed -- the checker for the product's shard-and-reduce entry point.
+int rto_par_cast_multi(rto_scene* const* scenes, int n_scenes, const rto_camera* camera, const rto_params* params,
+                       float* out_rgb, rto_stats* stats) {
+  if (!scenes || n_scenes <= 0 || !camera || !params || !out_rgb) return fail(-1, "null argument");
+  if (params->nranks > 1u) return fail(-1, "rto_par_cast_multi shards by itself");
+  const size_t n = (size_t)params->nx * params->ny * 3;
+  std::vector<float> part(n);
+  for (size_t i = 0; i < n; i++) out_rgb[i] = 0.f;
+  rto_stats total{};
+  for (int i = 0; i < n_scenes; i++) {
+    if (!scenes[i]) return fail(-1, "null scene handle");
+    rto_params p = *params;
+    p.rank = (uint32_t)i, p.nranks = (uint32_t)n_scenes;
+    std::fill(part.begin(), part.end(), 0.f);
+    rto_stats st{};
+    int rc = rto_par_cast(scenes[i], camera, &p, part.data(), stats ? &st : nullptr, 0);
+    if (rc) return rc;
+    for (size_t k = 0; k < n; k++) out_rgb[k] = out_rgb[k] + part[k];
+    total.samples += st.samples, total.aabb_tests += st.aabb_tests, total.prim_tests += st.prim_tests;
+    total.shaded_hits += st.shaded_hits, total.rays += st.rays, total.draws += st.draws;
+  }
+  if (stats) {
+    total.struct_size = stats->struct_size;
+    *stats = total;
   }
   return 0;
 }

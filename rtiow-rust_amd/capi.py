@@ -72,7 +72,7 @@ ABI_SYMBOLS = [
     "material_isotropic", "object_sphere", "object_rect", "object_flip_normals", "object_translate",
     "object_scale", "object_rotate_y", "object_and", "object_rect_prism", "object_linear_move",
     "object_constant_medium", "object_bvh", "object_bvh_sah", "camera_look", "scene_create", "scene_destroy",
-    "scene_info", "par_cast", "par_cast_device", "debug_hit_top", "debug_samples", "debug_math", "debug_flatten", "tonemap", "tonemap_device",
+    "scene_info", "par_cast", "par_cast_device", "par_cast_multi", "debug_hit_top", "debug_samples", "debug_math", "debug_flatten", "tonemap", "tonemap_device",
 ]
 
 
@@ -129,6 +129,8 @@ class Backend:
         f("par_cast", C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), c_f32p, C.POINTER(Stats)])
         f("par_cast_device", C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_void_p,
                                        C.c_void_p, C.POINTER(Stats)])
+        f("par_cast_multi", C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Camera), C.POINTER(Params), c_f32p,
+                                      C.POINTER(Stats)])
         f("debug_flatten", C.c_int, [C.c_void_p, c_u32p, C.c_size_t, c_u32p, c_u32p, c_u32p, C.c_size_t])
         f("tonemap_device", C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p])
 
@@ -165,6 +167,18 @@ class Backend:
         self.check(self._camera_look(_f3(look_from), _f3(look_at), _f3(up), fov, aspect, aperture,
                                      focus_dist, exposure[0], exposure[1], C.byref(cam)))
         return cam
+
+    def par_cast_multi(self, scenes, camera, nx, ny, ns, seed=0xDEADBEEF, stats=False, **kw):
+        """rtg_par_cast_multi: one scene handle per device (the same world flattened on each), tiles sharded over
+        them, ONE RCCL reduce(sum) of the float3 framebuffer inside the library.  Returns the assembled frame."""
+        p = make_params(nx, ny, ns, seed=seed, flags=FLAG_COUNTERS if stats else 0, **kw)
+        out = np.zeros((ny, nx, 3), dtype=np.float32)
+        st = Stats()
+        st.struct_size = C.sizeof(Stats)
+        arr = (C.c_void_p * len(scenes))(*[s.h for s in scenes])
+        self.check(self._par_cast_multi(arr, len(scenes), C.byref(camera), C.byref(p), out.ctypes.data_as(c_f32p),
+                                        C.byref(st)))
+        return (out, st.as_dict()) if stats else out
 
     def tonemap(self, img, device=0):
         """print_ppm's sqrt-gamma + `(255.99 * x) as i32` clamp (lib.rs:348-356) -> uint8 array of img's shape."""

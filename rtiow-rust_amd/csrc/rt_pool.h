@@ -49,28 +49,10 @@ enum PoolField : uint32_t {
 // shards, small images).  A work item is then (pixel, chunk of `chunk` consecutive samples); every
 // sample colour goes to an HBM scratch laid out [sample][pixel-work-index] and fold_samples_kernel
 // adds them per pixel IN SAMPLE ORDER afterwards -- the same left fold as lib.rs:365-374, bit for bit.
-struct ChunkMode {
-  float* scratch;      // null = off: a slot folds its pixel's samples itself
-  uint32_t chunk;      // samples per work item
-  uint32_t n_chunks;   // work items per pixel
-  uint32_t pix_work;   // pixel work items of this rank (tiles x tile area, incl. out-of-image padding)
-  // Cost-ordered queue ("longest processing time first"), lpt != null.  The end of a frame is a chain
-  // problem, not a throughput problem: a path that runs into the bounce cap (glass: ~0.2 % of book-1's
-  // samples) needs 51 dependent traverse + scatter generations, and the ones that START late finish
-  // ~1.2 ms after the queue is empty (measured: fixed cost per C2 launch 1.69 ms at cap 50, 0.46 ms at
-  // cap 4).  So the first `phase1` chunks run in natural order while every scatter event is counted per
-  // 256-pixel block; during the last of them each reservation files its block under one of 64
-  // logarithmic cost classes; the remaining chunks run block-major, classes in descending cost order:
-  // long-path-prone blocks first, sky last.  Order never changes results (per-event RNG streams,
-  // ordered fold).
-  const struct LptQueue* lpt;
-  uint32_t lpt_samples;  // samples [0, lpt_samples) of every pixel belong to phase 1 (0 = off)
-  uint32_t lpt_deep;     // a scatter event counts towards its block's cost from this bounce on
-};
 constexpr uint32_t LPT_BLOCK = 256;   // pixels per cost block = WORK_BLOCK
 constexpr uint32_t LPT_CLASSES = 64;  // one per lane
 constexpr uint32_t LPT_CTL = 80;      // count[64], [64] = blocks filed so far
-struct LptQueue {       // lives in device memory: the kernels touch it once per 256-item reservation
+struct LptQueue {       // descriptor (passed by value inside ChunkMode); cost / ctl / list live in device memory
   uint32_t* cost;       // [n_blocks] scatter events per block during phase 1
   uint32_t* ctl;        // [LPT_CTL]
   uint32_t* list;       // [LPT_CLASSES][n_blocks] blocks of each class, in filing order
@@ -82,6 +64,25 @@ struct LptQueue {       // lives in device memory: the kernels touch it once per
   uint32_t shift;       // classes are merged in groups of 1 << shift
 };
 
+struct ChunkMode {
+  float* scratch;      // null = off: a slot folds its pixel's samples itself
+  uint32_t chunk;      // samples per work item
+  uint32_t n_chunks;   // work items per pixel
+  uint32_t pix_work;   // pixel work items of this rank (tiles x tile area, incl. out-of-image padding)
+  // Cost-ordered queue ("longest processing time first"), lpt_on != 0.  The end of a frame is a chain
+  // problem, not a throughput problem: a path that runs into the bounce cap (glass: ~0.2 % of book-1's
+  // samples) needs 51 dependent traverse + scatter generations, and the ones that START late finish
+  // ~1.2 ms after the queue is empty (measured: fixed cost per C2 launch 1.69 ms at cap 50, 0.46 ms at
+  // cap 4).  So the first `phase1` chunks run in natural order while every scatter event is counted per
+  // 256-pixel block; during the last of them each reservation files its block under one of 64
+  // logarithmic cost classes; the remaining chunks run block-major, classes in descending cost order:
+  // long-path-prone blocks first, sky last.  Order never changes results (per-event RNG streams,
+  // ordered fold).
+  LptQueue lpt;          // by value: a kernel argument, so a launch never reads a descriptor another launch may rewrite
+  uint32_t lpt_on;       // 0: natural order throughout
+  uint32_t lpt_samples;  // samples [0, lpt_samples) of every pixel belong to phase 1 (0 = off)
+  uint32_t lpt_deep;     // a scatter event counts towards its block's cost from this bounce on
+};
 RT_DEV uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // phase 1: lanes with `on` add one to their block's cost -- one atomic per distinct block of the wave
@@ -91,7 +92,7 @@ RT_DEV void lpt_count(const ChunkMode& cm, bool on, uint32_t blk) {
   while (todo) {
     const uint32_t b0 = __builtin_amdgcn_readlane(blk, (uint32_t)__builtin_ctzll(todo));
     const uint64_t same = __builtin_amdgcn_ballot_w64(on && blk == b0);
-    if (on && blk == b0 && lane_rank(same) == 0u) atomicAdd(&cm.lpt->cost[b0], (uint32_t)__builtin_popcountll(same));
+    if (on && blk == b0 && lane_rank(same) == 0u) atomicAdd(&cm.lpt.cost[b0], (uint32_t)__builtin_popcountll(same));
     todo &= ~same;
   }
 }
@@ -99,7 +100,7 @@ RT_DEV void lpt_count(const ChunkMode& cm, bool on, uint32_t blk) {
 // A wave reserved work items [base, base + WORK_BLOCK): they all belong to one chunk and one 256-pixel
 // block (pix_work is a multiple of 256).  Returns the chunk; item w is pixel work index w + delta.
 RT_DEV uint32_t lpt_reservation(const ChunkMode& cm, uint32_t base, uint32_t lane, uint32_t& delta, bool& ready) {
-  const LptQueue* q = cm.lpt;
+  const LptQueue* q = cm.lpt_on ? &cm.lpt : nullptr;
   if (q == nullptr || base < q->phase2_base) {
     const uint32_t c = base / cm.pix_work;
     delta = 0u - c * cm.pix_work;

@@ -4,10 +4,15 @@
 // returns RTG_ERR_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and enums only: librccl is dlopen()ed by rtg_par_cast_multi, never linked
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -155,6 +160,7 @@ struct rtg_scene {
   void* buffers[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   unsigned long long* d_counters = nullptr;  // [0..4] N/P/H/rays/draws, [7] = work-queue head (persistent kernel)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t own_stream = nullptr;  // rtg_par_cast_multi: this scene's launch stream (created on first use)
   int num_cus = 0;
   float* d_frame = nullptr;     // rtg_par_cast: device staging frame for host framebuffers
   size_t frame_bytes = 0;
@@ -167,7 +173,7 @@ struct rtg_scene {
   int force_chunks = 0;        // RTG_CHUNKS: 0 = automatic
   uint32_t* d_lpt = nullptr;   // cost-ordered work queue (rt_pool.h LptQueue)
   size_t lpt_bytes = 0;
-  LptQueue lpt_desc{};         // what the descriptor slot of d_lpt holds
+  LptQueue lpt_desc{};         // descriptor of the last launch (RTG_VERBOSE histogram)
   int ray_lds = 1;             // RTG_RAY_LDS=0: all slot fields in global memory
   int lpt = 2;                 // RTG_LPT=0: natural order throughout; 1 / 2 = LptQueue::mode
   int lpt_deep = 4;            // RTG_LPT_DEEP: scatter events at bounce >= this make up a block's cost
@@ -237,7 +243,8 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
   const int bt = s->pool_threads;
   const uint32_t waves = (uint32_t)bt / 64;
   // sample-chunk mode (see rt_pool.h)
-  ChunkMode cm{nullptr, d.ns, 1, (uint32_t)pix_work};
+  ChunkMode cm{};
+  cm.scratch = nullptr, cm.chunk = d.ns, cm.n_chunks = 1, cm.pix_work = (uint32_t)pix_work;
   {
     // Default: one sample per work item.  Work items are then ~100x more numerous than path slots, so
     // the end-of-frame tail (slots finishing their last item while the queue is empty) is negligible;
@@ -321,7 +328,8 @@ static hipError_t grow(void** buf, size_t* have, size_t need) {
 // Cost-ordered work queue (rt_pool.h, ChunkMode): enabled when the frame has enough chunks for a measuring
 // phase and enough blocks to order; the buffers are re-zeroed on the launch stream every call.
 static hipError_t setup_lpt(rtg_scene* s, ChunkMode& cm, uint64_t capacity, hipStream_t stream) {
-  cm.lpt = nullptr, cm.lpt_samples = 0, cm.lpt_deep = 0;
+  memset(&cm.lpt, 0, sizeof(cm.lpt));
+  cm.lpt_on = 0, cm.lpt_samples = 0, cm.lpt_deep = 0;
   const uint32_t n_blocks = cm.pix_work / LPT_BLOCK;
   if (!s->lpt || !cm.scratch || cm.n_chunks < 6 || n_blocks < 64 || n_blocks > 65536 || cm.pix_work % LPT_BLOCK) return hipSuccess;
   // Phase 1 must outlast the first fill of the pools (`capacity` paths in flight) by enough for the
@@ -329,27 +337,20 @@ static hipError_t setup_lpt(rtg_scene* s, ChunkMode& cm, uint64_t capacity, hipS
   uint32_t phase1 = std::max<uint32_t>(std::min(8u, std::max(2u, cm.n_chunks / 8u)), (uint32_t)((2 * capacity + cm.pix_work - 1) / cm.pix_work));
   if (s->lpt_phase1 > 0) phase1 = (uint32_t)s->lpt_phase1;
   if (phase1 < 1 || phase1 > cm.n_chunks / 3) return hipSuccess;
-  // layout: [descriptor, 64 B] [cost n] [ctl LPT_CTL] [list LPT_CLASSES x n]
-  const size_t words = 16 + (size_t)n_blocks * (1 + LPT_CLASSES) + LPT_CTL;
-  if (words * sizeof(uint32_t) > s->lpt_bytes) memset(&s->lpt_desc, 0, sizeof(s->lpt_desc));
+  // device buffers: [cost n] [ctl LPT_CTL] [list LPT_CLASSES x n]; the descriptor itself travels as a kernel argument
+  const size_t words = (size_t)n_blocks * (1 + LPT_CLASSES) + LPT_CTL;
   hipError_t e = grow((void**)&s->d_lpt, &s->lpt_bytes, words * sizeof(uint32_t));
   if (e != hipSuccess) return e;
-  LptQueue q;
-  memset(&q, 0, sizeof(q));
-  static_assert(sizeof(LptQueue) <= 64, "descriptor slot");
-  q.cost = s->d_lpt + 16, q.ctl = q.cost + n_blocks, q.list = q.ctl + LPT_CTL;
+  LptQueue& q = cm.lpt;
+  q.cost = s->d_lpt, q.ctl = q.cost + n_blocks, q.list = q.ctl + LPT_CTL;
   q.n_blocks = n_blocks, q.phase1 = phase1;
   q.phase2_base = phase1 * cm.pix_work;
   q.span = LPT_BLOCK * (cm.n_chunks - phase1);
   q.mode = (uint32_t)s->lpt, q.shift = (uint32_t)s->lpt_shift;
-  if (memcmp(&q, &s->lpt_desc, sizeof(q)) != 0) {  // the descriptor only changes with the frame geometry
-    e = hipMemcpy(s->d_lpt, &q, sizeof(q), hipMemcpyHostToDevice);
-    if (e != hipSuccess) return e;
-    s->lpt_desc = q;
-  }
+  s->lpt_desc = q;
   e = hipMemsetAsync(q.cost, 0, ((size_t)n_blocks + LPT_CTL) * sizeof(uint32_t), stream);
   if (e != hipSuccess) return e;
-  cm.lpt = reinterpret_cast<const LptQueue*>(s->d_lpt);
+  cm.lpt_on = 1;
   cm.lpt_samples = phase1 * cm.chunk;
   cm.lpt_deep = (uint32_t)s->lpt_deep;
   return hipSuccess;
@@ -375,7 +376,8 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
   const uint32_t waves = (uint32_t)bt / 64;
   hipError_t e = grow((void**)&s->d_scratch, &s->scratch_bytes, scratch_need);
   if (e != hipSuccess) return e;
-  ChunkMode cm{s->d_scratch, 1u, d.ns, (uint32_t)pix_work};
+  ChunkMode cm{};
+  cm.scratch = s->d_scratch, cm.chunk = 1u, cm.n_chunks = d.ns, cm.pix_work = (uint32_t)pix_work;
   uint32_t* queue = (uint32_t*)(s->d_counters + 7);
   e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
@@ -717,6 +719,7 @@ void rtg_scene_destroy(rtg_scene* s) {
   if (s->d_frame) (void)hipFree(s->d_frame);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
+  if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
   delete s;
 }
 
@@ -813,6 +816,12 @@ static int check_params(const rtg_scene* s, const rtg_camera* camera, const rtg_
   if ((uint64_t)p->nx * p->ny > 0xffffffffull) return fail(RTG_ERR_INVALID, "image too large for 32-bit pixel index");
   if (!(camera->exposure_start < camera->exposure_end))  // camera.rs:55 / rand assert
     return fail(RTG_ERR_RANGE, "Uniform::sample_single called with low >= high");
+  // rand 0.6.5's sample_single panics on non-finite bounds once its scale is not finite ("non-finite boundaries");
+  // with scale = inf the retry loop of SampleRng::gen_range would never accept a value (a hung GPU)
+  if (!std::isfinite(camera->exposure_start) || !std::isfinite(camera->exposure_end))
+    return fail(RTG_ERR_RANGE, "Uniform::sample_single called with non-finite boundaries");
+  if (!std::isfinite(camera->exposure_end - camera->exposure_start))  // rand would shrink the scale here; not restated
+    return fail(RTG_ERR_RANGE, "exposure range wider than f32::MAX is not supported");
   DevParams d;
   d.nx = p->nx, d.ny = p->ny, d.ns = p->ns, d.max_bounces = p->max_bounces;
   d.t_near = p->t_near;
@@ -918,6 +927,161 @@ int rtg_par_cast(rtg_scene* s, const rtg_camera* camera, const rtg_params* param
     if (e != hipSuccess) rc = hip_fail(e, "render / copy back");
   }
   return rc;
+}
+
+// ---- single-process multi-GPU par_cast ---------------------------------------------------
+// RCCL is dlopen()ed on first use with more than one distinct device, so librtiow_gpu.so carries no link-time
+// dependency on it and one-GPU hosts never load it.
+namespace {
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::map<std::vector<int>, std::vector<ncclComm_t>> comms;  // one clique per device list, created once
+  std::mutex mu;
+};
+Rccl g_rccl;
+
+bool rccl_load(std::string* why) {
+  if (g_rccl.lib) return true;
+  // an already-loaded librccl (e.g. the one a host framework ships) first, then the ROCm installation's
+  const char* names[] = {"librccl.so", "librccl.so.1"};
+  void* h = nullptr;
+  for (const char* n : names)
+    if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+  if (!h)
+    for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+      if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+  if (!h) {
+    *why = std::string("librccl not loadable: ") + (dlerror() ? dlerror() : "?");
+    return false;
+  }
+  auto sym = [&](const char* n) { return dlsym(h, n); };
+  g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))sym("ncclCommInitAll");
+  g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+  g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
+  g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
+  g_rccl.Reduce = (decltype(g_rccl.Reduce))sym("ncclReduce");
+  g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+  if (!g_rccl.CommInitAll || !g_rccl.GroupStart || !g_rccl.GroupEnd || !g_rccl.Reduce || !g_rccl.GetErrorString) {
+    *why = "librccl lacks ncclCommInitAll / ncclGroupStart / ncclGroupEnd / ncclReduce";
+    return false;
+  }
+  g_rccl.lib = h;
+  return true;
+}
+
+__global__ void add_frames_kernel(size_t n, float* __restrict__ dst, const float* __restrict__ src) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = dst[i] + src[i];  // every pixel has ONE non-zero contributor: x + 0 is exact
+}
+}  // namespace
+
+int rtg_par_cast_multi(rtg_scene* const* scenes, int n_scenes, const rtg_camera* camera, const rtg_params* params,
+                       float* out_rgb, rtg_stats* stats) {
+  if (!scenes || n_scenes <= 0 || !camera || !params || !out_rgb) return fail(RTG_ERR_INVALID, "null argument");
+  if (params->struct_size != sizeof(rtg_params)) return fail(RTG_ERR_INVALID, "rtg_params.struct_size mismatch");
+  if (params->nranks > 1u) return fail(RTG_ERR_INVALID, "rtg_par_cast_multi shards by itself: params.rank / nranks must be 0 / 0|1");
+  if (stats && stats->struct_size != sizeof(rtg_stats)) return fail(RTG_ERR_INVALID, "rtg_stats.struct_size mismatch");
+  for (int i = 0; i < n_scenes; i++)
+    if (!scenes[i]) return fail(RTG_ERR_INVALID, "null scene handle");
+  const size_t n_floats = (size_t)params->nx * params->ny * 3;
+  const size_t bytes = n_floats * sizeof(float);
+  const bool count = stats && (params->flags & RTG_FLAG_COUNTERS);
+  // (1) every scene renders ITS tiles (tile % n_scenes == i) into its own zero-filled full frame, on its own stream
+  for (int i = 0; i < n_scenes; i++) {
+    rtg_scene* s = scenes[i];
+    HIP_TRY(hipSetDevice(s->device));
+    if (!s->own_stream) HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+    hipError_t e = grow((void**)&s->d_frame, &s->frame_bytes, bytes ? bytes : 16);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(framebuffer)");
+    HIP_TRY(hipMemsetAsync(s->d_frame, 0, bytes, s->own_stream));
+    rtg_params p = *params;
+    p.rank = (uint32_t)i, p.nranks = (uint32_t)n_scenes;
+    DevParams d;
+    int rc = check_params(s, camera, &p, &d);
+    if (rc) return rc;
+    if (count) {
+      HIP_TRY(hipMemsetAsync(s->d_counters, 0, 7 * sizeof(unsigned long long), s->own_stream));
+      HIP_TRY(hipMemsetAsync(s->d_counters + 8, 0, 24 * sizeof(unsigned long long), s->own_stream));
+    }
+    HIP_TRY(hipEventRecord(s->ev0, s->own_stream));
+    const DevCamera cam = to_dev(camera);
+    HIP_TRY(count ? launch_render<true>(s, cam, d, s->d_frame, s->own_stream) : launch_render<false>(s, cam, d, s->d_frame, s->own_stream));
+    HIP_TRY(hipEventRecord(s->ev1, s->own_stream));
+  }
+  // (2) scenes that share a device with an earlier one are summed there; one frame per DISTINCT device remains
+  std::vector<int> devs;          // distinct devices in order of first appearance
+  std::vector<rtg_scene*> heads;  // the scene holding each device's partial frame
+  for (int i = 0; i < n_scenes; i++) {
+    rtg_scene* s = scenes[i];
+    size_t k = 0;
+    while (k < devs.size() && devs[k] != s->device) k++;
+    if (k == devs.size()) {
+      devs.push_back(s->device), heads.push_back(s);
+      continue;
+    }
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->own_stream));
+    hipLaunchKernelGGL(add_frames_kernel, dim3((uint32_t)((n_floats + 255) / 256)), dim3(256), 0, heads[k]->own_stream, n_floats,
+                       heads[k]->d_frame, s->d_frame);
+    HIP_TRY(hipGetLastError());
+  }
+  // (3) ONE collective over the distinct devices: reduce(sum) of the float3 framebuffer to the first device (xGMI)
+  if (devs.size() > 1) {
+    std::lock_guard<std::mutex> lock(g_rccl.mu);
+    std::string why;
+    if (!rccl_load(&why)) return fail(RTG_ERR_DEVICE, why);
+    auto it = g_rccl.comms.find(devs);
+    if (it == g_rccl.comms.end()) {
+      std::vector<ncclComm_t> c(devs.size());
+      ncclResult_t r = g_rccl.CommInitAll(c.data(), (int)devs.size(), devs.data());
+      if (r != ncclSuccess) return fail(RTG_ERR_DEVICE, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r));
+      it = g_rccl.comms.emplace(devs, std::move(c)).first;
+    }
+    ncclResult_t r = g_rccl.GroupStart();
+    for (size_t k = 0; k < devs.size() && r == ncclSuccess; k++) {
+      HIP_TRY(hipSetDevice(devs[k]));
+      r = g_rccl.Reduce(heads[k]->d_frame, heads[k]->d_frame, n_floats, ncclFloat, ncclSum, 0, it->second[k], heads[k]->own_stream);
+    }
+    ncclResult_t r2 = g_rccl.GroupEnd();
+    if (r == ncclSuccess) r = r2;
+    if (r != ncclSuccess) return fail(RTG_ERR_DEVICE, std::string("ncclReduce: ") + g_rccl.GetErrorString(r));
+  }
+  // (4) wait, copy the assembled frame out, gather stats (kernel time = the slowest shard)
+  for (rtg_scene* h : heads) {
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->own_stream));
+  }
+  HIP_TRY(hipSetDevice(heads[0]->device));
+  HIP_TRY(hipMemcpy(out_rgb, heads[0]->d_frame, bytes, hipMemcpyDeviceToHost));
+  if (stats) {
+    rtg_stats total{};
+    total.struct_size = sizeof(rtg_stats);
+    for (int i = 0; i < n_scenes; i++) {
+      rtg_scene* s = scenes[i];
+      HIP_TRY(hipSetDevice(s->device));
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+      total.kernel_ms = std::max(total.kernel_ms, ms);
+      rtg_params p = *params;
+      p.rank = (uint32_t)i, p.nranks = (uint32_t)n_scenes;
+      DevParams d;
+      (void)check_params(s, camera, &p, &d);
+      total.samples += owned_pixels(d) * d.ns;
+      if (count) {
+        unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        HIP_TRY(hipMemcpy(h, s->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+        total.aabb_tests += h[0], total.prim_tests += h[1], total.shaded_hits += h[2], total.rays += h[3], total.draws += h[4];
+      }
+    }
+    *stats = total;
+  }
+  return RTG_OK;
 }
 
 // ---- probes --------------------------------------------------------------------------------------

@@ -29,6 +29,32 @@ def test_every_declared_symbol_is_exported(pkg):
     assert sorted("rtg_" + s for s in pkg.capi.ABI_SYMBOLS) == names
 
 
+def test_rust_sys_crate_declares_every_header_symbol():
+    """No Rust toolchain exists here, so the `-sys` crate cannot be compiled; what can be checked is that it declares
+    exactly the header's entry points, each with the header's number of arguments, and the three repr(C) structs with
+    the header's field order."""
+    rs = open(os.path.join(ROOT, "rtiow-rust_amd", "host", "rust", "rtiow-gpu-sys", "src", "lib.rs")).read()
+    hdr = open(os.path.join(ROOT, "include", "rtiow_gpu.h")).read()
+    hdr_nc = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    rs_nc = re.sub(r"//[^\n]*", "", rs)
+    c_fns = {m.group(1): m.group(2) for m in re.finditer(r"\b(rtg_[a-z_0-9]+)\s*\(([^)]*)\)\s*;", hdr_nc)}
+    rs_fns = {m.group(1): m.group(2) for m in re.finditer(r"pub fn (rtg_[a-z_0-9]+)\s*\(([^)]*)\)", rs_nc, flags=re.S)}
+    assert sorted(c_fns) == sorted(rs_fns) == header_symbols()
+
+    def argc(a):
+        a = a.strip()
+        return 0 if a in ("", "void") else len([x for x in a.split(",") if x.strip()])
+    for name in c_fns:
+        assert argc(c_fns[name]) == argc(rs_fns[name]), name
+    for struct in ("rtg_camera", "rtg_params", "rtg_stats"):
+        c_body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), hdr_nc, flags=re.S).group(1)
+        c_fields = [f for decl in c_body.split(";") if decl.strip()
+                    for f in re.findall(r"([a-z_0-9]+)(?:\[\d+\])?\s*(?:,|$)", decl.strip().split(None, 1)[1])]
+        rs_body = re.search(r"pub struct %s \{(.*?)\n\}" % struct, rs_nc, flags=re.S).group(1)
+        rs_fields = re.findall(r"pub ([a-z_0-9]+):", rs_body)
+        assert c_fields == rs_fields, (struct, c_fields, rs_fields)
+
+
 def test_oracle_mirrors_the_abi(pkg, oracle):
     for s in pkg.capi.ABI_SYMBOLS:
         if s in ("device_count", "scene_info", "par_cast_device", "debug_flatten", "tonemap_device"):

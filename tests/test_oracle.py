@@ -222,3 +222,31 @@ def test_sah_tree_gives_the_reference_image(pkg, oracle):
     b_, sb = sah.par_cast(cam2, nx, ny, 6, stats=True)
     assert_bit_equal(a, b_, "sah vs median tree")
     assert sb["rays"] == sa["rays"] and sb["aabb_tests"] < 0.75 * sa["aabb_tests"]
+
+
+def test_par_cast_multi_mirror_equals_one_frame(pkg, oracle):
+    """rto_par_cast_multi (the checker for rtg_par_cast_multi): n shard renders summed == the unsharded frame."""
+    from scene_cases import build_case
+    scenes = []
+    for _ in range(3):
+        s, cam, nx, ny, ns = build_case(pkg, oracle, "book1", 64, 48)
+        scenes.append(s)
+    whole, st1 = scenes[0].par_cast(cam, nx, ny, ns, stats=True)
+    multi, stn = oracle.par_cast_multi(scenes, cam, nx, ny, ns, stats=True)
+    assert_bit_equal(multi, whole, "3 shards")
+    for k in ("samples", "aabb_tests", "prim_tests", "shaded_hits", "rays", "draws"):
+        assert st1[k] == stn[k], k
+    with pytest.raises(pkg.RtError):
+        oracle.par_cast_multi(scenes, cam, nx, ny, ns, rank=1, nranks=2)   # the call shards by itself
+
+
+def test_non_finite_exposure_is_refused(pkg, oracle):
+    """rand 0.6.5 panics on non-finite gen_range bounds; scale = inf would never accept a value."""
+    b = oracle.builder()
+    world, cam, _ = pkg.scenes.cornell_box_scene(b, 8, 8)
+    sc = b.scene(world)
+    for e0, e1 in ((0.0, float("inf")), (float("-inf"), 0.0), (-3e38, 3e38), (float("nan"), 1.0), (1.0, 1.0)):
+        cam.exposure_start, cam.exposure_end = e0, e1
+        with pytest.raises(pkg.RtError) as e:
+            sc.par_cast(cam, 8, 8, 1)
+        assert e.value.code == -4, (e0, e1)

@@ -132,6 +132,41 @@ def test_gen_range_assertion(pkg, gpu):
     assert e.value.code == -4
 
 
+def test_non_finite_exposure_is_refused(pkg, gpu):
+    """exposure_end = inf or an overflowing (end - start): scale = inf in gen_range would spin every lane of the
+    persistent kernel forever -> RTG_ERR_RANGE up front (rand 0.6.5 panics "non-finite boundaries")."""
+    b = gpu.builder()
+    world, cam, _ = pkg.scenes.cornell_box_scene(b, 16, 16)
+    sc = b.scene(world)
+    for e0, e1 in ((0.0, float("inf")), (float("-inf"), 0.0), (-3e38, 3e38), (float("nan"), 1.0)):
+        cam.exposure_start, cam.exposure_end = e0, e1
+        with pytest.raises(pkg.RtError) as e:
+            sc.par_cast(cam, 16, 16, 1)
+        assert e.value.code == -4, (e0, e1)
+
+
+@pytest.mark.parametrize("name,nx,ny,ns", [("book1", 176, 112, 12), ("book2", 96, 80, 6), ("cornell", 64, 64, 8)])
+def test_par_cast_multi_in_library_shard_and_reduce(pkg, gpu, oracle, name, nx, ny, ns):
+    """rtg_par_cast_multi: one scene handle per device, tiles sharded inside the library, frames summed.
+    This box has ONE GPU, so the handles share device 0 (summed on the device; the RCCL clique needs >= 2 distinct
+    devices) -- 1, 2, 3 and 8 handles must all give the one-GPU frame and the oracle's, counters included."""
+    so, cam_o, _, _, _ = build_case(pkg, oracle, name, nx, ny)
+    ref, st_o = so.par_cast(cam_o, nx, ny, ns, stats=True)
+    for n in (1, 2, 3, 8):
+        scenes = []
+        for _ in range(n):
+            sg, cam_g, _, _, _ = build_case(pkg, gpu, name, nx, ny)
+            scenes.append(sg)
+        img, st = gpu.par_cast_multi(scenes, cam_g, nx, ny, ns, stats=True)
+        assert_bit_equal(img, ref, "%s, %d handles" % (name, n))
+        for k in ("samples", "aabb_tests", "prim_tests", "shaded_hits", "rays", "draws"):
+            assert st[k] == st_o[k], (name, n, k)
+        assert st["kernel_ms"] > 0
+        assert_bit_equal(gpu.par_cast_multi(scenes, cam_g, nx, ny, ns), ref, "%s, %d handles (timed variant)" % (name, n))
+    with pytest.raises(pkg.RtError):
+        gpu.par_cast_multi(scenes, cam_g, nx, ny, ns, rank=1, nranks=2)
+
+
 def test_ragged_image_sizes(pkg, gpu, oracle):
     """Sizes that are not multiples of the 16x16 block / 8x8 wave tile, and 1-pixel images."""
     for (nx, ny) in [(1, 1), (17, 9), (33, 47), (15, 64)]:
