@@ -140,6 +140,10 @@ int rtg_camera_look(const float look_from[3], const float look_at[3], const floa
  * one-element list holding the rtg_object_bvh handle (identical arithmetic). */
 int rtg_scene_create(rtg_builder* b, const rtg_id* world, size_t n, int device, rtg_scene** out);
 void rtg_scene_destroy(rtg_scene* s);
+/* Scheduling / measurement switches of one scene handle -- kernel generation, cost-ordered work queue, pool
+ * thresholds, workgroup size (names: DESIGN.md section 4 "Knobs").  None of them changes a bit of the result.  The
+ * library reads no environment variable for these. */
+int rtg_scene_set_option(rtg_scene* s, const char* name, int value);
 /* size of the flattened program (for DESIGN.md's byte accounting / tests) */
 int rtg_scene_info(const rtg_scene* s, uint32_t* n_instructions, uint32_t* n_materials,
                    uint32_t* n_textures, uint64_t* hbm_bytes);

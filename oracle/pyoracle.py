@@ -6,7 +6,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboracle.so")
+# RTIOW_ORACLE_LIB: the sanitizer leg (tests/test_oracle_sanitized.py) loads oracle/_san/liboracle_san.so instead
+LIB_PATH = os.environ.get("RTIOW_ORACLE_LIB", os.path.join(_HERE, "liboracle.so"))
 _backend = None
 
 

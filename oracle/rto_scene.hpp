@@ -47,7 +47,8 @@ inline int32_t f32_as_i32(float f) {
   return (int32_t)f;
 }
 
-// perlin.rs:49-64
+// perlin.rs:49-64.  `(i + di) & 255` on i32: `as i32` saturates for |p| >= 2^31 and the release build's `+` wraps --
+// done in u32 here (same low 8 bits, no signed-overflow UB)
 inline float perlin_noise(const PerlinTables& T, Vec3 p) {
   Vec3 ijk(std::floor(p.x), std::floor(p.y), std::floor(p.z));
   Vec3 uvw = p - ijk;
@@ -55,9 +56,9 @@ inline float perlin_noise(const PerlinTables& T, Vec3 p) {
   for (int di = 0; di < 2; di++)
     for (int dj = 0; dj < 2; dj++)
       for (int dk = 0; dk < 2; dk++) {
-        uint8_t ix = T.perm_x[(uint32_t)(f32_as_i32(ijk.x) + di) & 255u];
-        uint8_t iy = T.perm_y[(uint32_t)(f32_as_i32(ijk.y) + dj) & 255u];
-        uint8_t iz = T.perm_z[(uint32_t)(f32_as_i32(ijk.z) + dk) & 255u];
+        uint8_t ix = T.perm_x[((uint32_t)f32_as_i32(ijk.x) + (uint32_t)di) & 255u];
+        uint8_t iy = T.perm_y[((uint32_t)f32_as_i32(ijk.y) + (uint32_t)dj) & 255u];
+        uint8_t iz = T.perm_z[((uint32_t)f32_as_i32(ijk.z) + (uint32_t)dk) & 255u];
         corners[di][dj][dk] = T.vecs[ix ^ iy ^ iz];
       }
   return trilinear_interp(corners, uvw);

@@ -72,7 +72,7 @@ ABI_SYMBOLS = [
     "material_isotropic", "object_sphere", "object_rect", "object_flip_normals", "object_translate",
     "object_scale", "object_rotate_y", "object_and", "object_rect_prism", "object_linear_move",
     "object_constant_medium", "object_bvh", "object_bvh_sah", "camera_look", "scene_create", "scene_destroy",
-    "scene_info", "par_cast", "par_cast_device", "par_cast_multi", "debug_hit_top", "debug_samples", "debug_math", "debug_flatten", "tonemap", "tonemap_device",
+    "scene_set_option", "scene_info", "par_cast", "par_cast_device", "par_cast_multi", "debug_hit_top", "debug_samples", "debug_math", "debug_flatten", "tonemap", "tonemap_device",
 ]
 
 
@@ -125,6 +125,7 @@ class Backend:
     def _declare_render(self):
         f = self._fn
         f("device_count", C.c_int, [C.POINTER(C.c_int)])
+        f("scene_set_option", C.c_int, [C.c_void_p, C.c_char_p, C.c_int])
         f("scene_info", C.c_int, [C.c_void_p, c_u32p, c_u32p, c_u32p, C.POINTER(C.c_uint64)])
         f("par_cast", C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), c_f32p, C.POINTER(Stats)])
         f("par_cast_device", C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_void_p,
@@ -310,7 +311,9 @@ class Builder:
         arr = (C.c_uint32 * max(1, len(world)))(*world)
         h = C.c_void_p()
         self.be.check(self.be._scene_create(self.h, arr, len(world), device, C.byref(h)))
-        return self.be.scene_class(self.be, h, self)
+        sc = self.be.scene_class(self.be, h, self)
+        sc.apply_env_options()
+        return sc
 
 
 class Scene:
@@ -329,6 +332,22 @@ class Scene:
             self.close()
         except Exception:
             pass
+
+    # measurement / test hook: RTG_<OPTION>=<int> in the environment of the PYTHON process becomes
+    # rtg_scene_set_option(scene, "<option>", <int>) -- the library itself reads no environment variable
+    ENV_OPTIONS = ("kernel", "chunks", "lpt", "lpt_phase1", "lpt_deep", "lpt_shift", "ray_lds", "block", "wg_per_cu", "window",
+                   "box_leave", "refill_min", "gather_min", "run_ahead", "run_ahead_min", "sphere_min", "verbose")
+
+    def set_option(self, name, value):
+        self.be.check(self.be._scene_set_option(self.h, name.encode(), int(value)))
+
+    def apply_env_options(self):
+        if not hasattr(self.be, "_scene_set_option"):
+            return
+        for name in self.ENV_OPTIONS:
+            v = os.environ.get("RTG_" + name.upper())
+            if v is not None:
+                self.set_option(name, int(v))
 
     def info(self):
         a, b, c, d = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()

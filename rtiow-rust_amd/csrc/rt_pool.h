@@ -23,9 +23,35 @@
 // Scheduling never changes results: every (pixel, sample, event) has its own RNG stream and a pixel's
 // samples are folded in sample order.
 #pragma once
-#include "rt_persistent.h"
+#include "rt_trace.h"
 
 namespace rtg {
+
+constexpr uint32_t ST_NEED_PIXEL = 0, ST_GEN = 1, ST_TRAV = 2, ST_SHADE = 3, ST_DEAD = 4;
+constexpr uint32_t NO_HIT = 0xffffffffu;
+
+RT_DEV uint32_t lane_rank(uint64_t mask) {  // number of set bits below this lane
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// work item -> pixel.  Work items enumerate this rank's tiles (tile % nranks == rank) in order, each
+// tile as 8x8 blocks, so the 64 items a wave grabs at start form one coherent 8x8 block.
+RT_DEV bool work_to_pixel(const DevParams& P, uint32_t w, uint32_t& x, uint32_t& row) {
+  const uint32_t px_per_tile = P.tile_w * P.tile_h;
+  const uint32_t tiles_x = (P.nx + P.tile_w - 1u) / P.tile_w;
+  uint32_t k = w / px_per_tile, r = w - k * px_per_tile;
+  uint32_t tile = P.rank + k * P.nranks;
+  uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+  uint32_t blocks_x = P.tile_w >> 3;
+  uint32_t b = r >> 6, l = r & 63u;
+  uint32_t bx = b % blocks_x, by = b / blocks_x;
+  x = tx * P.tile_w + bx * 8u + (l & 7u);
+  row = ty * P.tile_h + by * 8u + (l >> 3);
+  return x < P.nx && row < P.ny;
+}
+
+#define RT_TICK() (COUNT ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull)
+
 
 #ifndef RT_POOL_SLOTS
 #define RT_POOL_SLOTS 144  // 8 global dwords x 144 slots x 4 096 waves = 2.4 MB per XCD: the slot rows stay in the 4 MB L2s

@@ -17,7 +17,6 @@
 #include <vector>
 
 #include "../../include/rtiow_gpu.h"
-#include "rt_persistent.h"
 #include "rt_pool.h"
 #include "rt_pool_full.h"
 #include "rt_trace.h"
@@ -174,18 +173,18 @@ struct rtg_scene {
   uint32_t* d_lpt = nullptr;   // cost-ordered work queue (rt_pool.h LptQueue)
   size_t lpt_bytes = 0;
   LptQueue lpt_desc{};         // descriptor of the last launch (RTG_VERBOSE histogram)
-  int ray_lds = 1;             // RTG_RAY_LDS=0: all slot fields in global memory
+  int verbose = 0;
+  int window = -1;             // full-feature kernel: records of the program staged in LDS (-1 = as many as fit)
+  int ray_lds = 1;             // 0: all slot fields in global memory
   int lpt = 2;                 // RTG_LPT=0: natural order throughout; 1 / 2 = LptQueue::mode
   int lpt_deep = 4;            // RTG_LPT_DEEP: scatter events at bounce >= this make up a block's cost
   int lpt_shift = 0;           // RTG_LPT_SHIFT: merge cost classes in groups of 1 << shift
   int lpt_phase1 = 0;          // RTG_LPT_PHASE1: chunks in natural order, 0 = n_chunks / 8 clamped to [2, 8]
-  // lean scenes: 3 = ray-pool kernel (rt_pool.h), 2 = persistent single-wave regeneration (rt_persistent.h),
-  // 1 = one-lane-per-pixel baseline (rt_trace.h).  Non-lean scenes always use 1.
+  // 3 = ray-pool kernels (rt_pool.h / rt_pool_full.h), 1 = one-lane-per-pixel baseline (rt_trace.h) for every scene
   int kernel_version = 3;
   PoolTuning pool_tune{36, 16, 32, 16, 16, 40};  // lean ray-pool kernel
   PoolTuning full_tune{20, 16, 32, 16, 16, 40};  // full-feature kernel (a service there also has hit records to move)
-  Tuning tune{24, 16, 8};
-  int block_threads = 512, wg_per_cu = 0;  // 0 = ask the occupancy API
+  int wg_per_cu = 0;                       // 0 = ask the occupancy API
   int full_threads = 0;                    // full-feature pool kernel: 0 = the variant's maximum (RTG_BLOCK overrides)
   int pool_threads = 1024;                 // lean ray-pool kernel: ONE 16-wave workgroup per CU shares one LDS copy of the program
 };
@@ -199,37 +198,6 @@ static uint64_t scratch_cap() {
 
 static uint64_t owned_pixels(const DevParams& d);
 static hipError_t setup_lpt(rtg_scene* s, ChunkMode& cm, uint64_t capacity, hipStream_t stream);
-
-// Lean scenes: persistent wavefronts pulling pixels from a work counter (rt_persistent.h).
-template <bool COUNT>
-static hipError_t launch_persistent(const rtg_scene* s, const DevCamera& cam, const DevParams& d, float* d_out,
-                                    hipStream_t stream) {
-  uint32_t tiles_x = (d.nx + d.tile_w - 1) / d.tile_w, tiles_y = (d.ny + d.tile_h - 1) / d.tile_h;
-  uint32_t tiles = tiles_x * tiles_y;
-  uint32_t owned = tiles > d.rank ? (tiles - d.rank + d.nranks - 1) / d.nranks : 0;
-  uint64_t total_work = (uint64_t)owned * d.tile_w * d.tile_h;
-  if (total_work > 0xfffffffeull) return hipErrorInvalidValue;
-  uint32_t* queue = (uint32_t*)(s->d_counters + 7);
-  hipError_t e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream);  // re-initialise every call
-  if (e != hipSuccess) return e;
-  size_t lds = (size_t)s->n_prog * 32 + (size_t)s->n_mat * 32;
-  bool use_lds = lds <= 64 * 1024;
-  auto kernel = use_lds ? render_lean_persistent<true, COUNT> : render_lean_persistent<false, COUNT>;
-  if (!use_lds) lds = 0;
-  int per_cu = s->wg_per_cu;
-  const int bt = s->block_threads;
-  if (per_cu <= 0) {
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, bt, lds);
-    if (e != hipSuccess) return e;
-  }
-  if (per_cu < 1) per_cu = 1;
-  uint64_t want = (total_work + bt - 1) / bt;
-  uint32_t grid = (uint32_t)std::min<uint64_t>(want ? want : 1, (uint64_t)s->num_cus * per_cu);
-  if (getenv("RTG_VERBOSE")) fprintf(stderr, "[rtg] persistent: grid %u x %d threads, %d WG/CU, lds %zu B\n", grid, bt, per_cu, lds);
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(bt), lds, stream, s->dev, cam, d, d_out, (uint32_t)total_work, queue,
-                     s->d_counters, s->tune);
-  return hipGetLastError();
-}
 
 // Lean scenes, ray-pool kernel (rt_pool.h): one persistent 1024-thread workgroup per CU.
 template <bool COUNT>
@@ -292,7 +260,7 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
   uint32_t grid = (uint32_t)std::min<uint64_t>(want ? want : 1, (uint64_t)s->num_cus * per_cu);
   e = setup_lpt(s, cm, (uint64_t)grid * waves * POOL, stream);
   if (e != hipSuccess) return e;
-  if (getenv("RTG_VERBOSE"))
+  if (s->verbose)
     fprintf(stderr, "[rtg] pool: grid %u x %d threads, %d WG/CU, lds %zu B (program staged: %d, rays in LDS: %d), %u chunk(s) of %u samples, cost-ordered queue after %u chunk(s)\n", grid,
             bt, per_cu, lds, (int)use_lds, (int)ray_lds, cm.n_chunks, cm.chunk, cm.lpt_samples / (cm.chunk ? cm.chunk : 1u));
   {
@@ -388,8 +356,8 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
   uint32_t window = s->n_prog;
   int prog = 1;
   if ((size_t)window * 32 + list_bytes > budget) window = (uint32_t)((budget - list_bytes) / 32), prog = 2;
-  if (const char* kv = getenv("RTG_WINDOW")) {
-    window = std::min<uint32_t>(s->n_prog, (uint32_t)atoi(kv));
+  if (s->window >= 0) {
+    window = std::min<uint32_t>(s->n_prog, (uint32_t)s->window);
     prog = window == 0 ? 0 : (window == s->n_prog ? 1 : 2);
   }
   const size_t lds = full_pool_lds_bytes(window, waves);
@@ -414,7 +382,7 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
   if (e != hipSuccess) return e;
   e = grow((void**)&s->d_stack, &s->stack_bytes, (size_t)grid * waves * MAX_XFORM_DEPTH * 6 * 64 * sizeof(float));
   if (e != hipSuccess) return e;
-  if (getenv("RTG_VERBOSE"))
+  if (s->verbose)
     fprintf(stderr, "[rtg] full pool: grid %u x %d threads, %d WG/CU, lds %zu B (program window: %u of %u records), cost-ordered queue after %u chunk(s)\n",
             grid, bt, per_cu, lds, window, s->n_prog, cm.lpt_samples);
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(bt), lds, stream, s->dev, cam, d, d_out, (uint32_t)total_work, queue,
@@ -438,7 +406,6 @@ static hipError_t launch_render(rtg_scene* s, const DevCamera& cam, const DevPar
     if (e != hipErrorNotSupported) return e;
   }
   if (geom == 0 && pool_ok) return launch_pool<COUNT>(s, cam, d, d_out, stream);
-  if (geom == 0 && s->kernel_version >= 2) return launch_persistent<COUNT>(s, cam, d, d_out, stream);
   uint32_t nbx = (d.nx + 15) / 16, nby = (d.ny + 15) / 16;
   dim3 grid(nbx * nby), block(256);
   if (geom == 0)
@@ -763,29 +730,41 @@ int rtg_scene_create(rtg_builder* b, const rtg_id* world, size_t n, int device, 
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->num_cus = prop.multiProcessorCount;
   if (s->num_cus <= 0) s->num_cus = 256;
-  if (const char* kv = getenv("RTG_KERNEL")) s->kernel_version = atoi(kv);  // A/B switches for measurements
-  if (const char* kv = getenv("RTG_CHUNKS")) s->force_chunks = atoi(kv);
-  if (const char* kv = getenv("RTG_LPT")) s->lpt = atoi(kv);
-  if (const char* kv = getenv("RTG_RAY_LDS")) s->ray_lds = atoi(kv);
-  if (const char* kv = getenv("RTG_LPT_PHASE1")) s->lpt_phase1 = atoi(kv);
-  if (const char* kv = getenv("RTG_LPT_DEEP")) s->lpt_deep = atoi(kv);
-  if (const char* kv = getenv("RTG_LPT_SHIFT")) s->lpt_shift = std::min(6, std::max(0, atoi(kv)));
-  if (const char* kv = getenv("RTG_BLOCK")) s->block_threads = s->pool_threads = s->full_threads = atoi(kv);
-  if (const char* kv = getenv("RTG_WG_PER_CU")) s->wg_per_cu = atoi(kv);
-  if (const char* kv = getenv("RTG_REGEN_MIN")) s->tune.regen_min = (uint32_t)atoi(kv);
-  if (const char* kv = getenv("RTG_SPHERE_MIN")) s->tune.sphere_min = (uint32_t)atoi(kv);
-  if (const char* kv = getenv("RTG_BOX_LEAVE")) s->tune.box_leave = s->pool_tune.box_leave = s->full_tune.box_leave = (uint32_t)atoi(kv);
-  if (const char* kv = getenv("RTG_REFILL_MIN")) s->pool_tune.refill_min = s->full_tune.refill_min = (uint32_t)atoi(kv);
-  if (const char* kv = getenv("RTG_GATHER_MIN")) s->pool_tune.gather_min = s->full_tune.gather_min = (uint32_t)atoi(kv);
-  if (const char* kv = getenv("RTG_RUN_AHEAD")) s->pool_tune.run_ahead = s->full_tune.run_ahead = (uint32_t)atoi(kv);
-  if (const char* kv = getenv("RTG_RUN_AHEAD_MIN")) s->pool_tune.run_ahead_min = s->full_tune.run_ahead_min = (uint32_t)atoi(kv);
-  if (const char* kv = getenv("RTG_SPHERE_MIN")) s->pool_tune.sphere_min = s->full_tune.sphere_min = (uint32_t)atoi(kv);
   if (hipMalloc((void**)&s->d_counters, 32 * sizeof(unsigned long long)) != hipSuccess ||
       hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
     rtg_scene_destroy(s);
     return fail(RTG_ERR_DEVICE, "scene: counter/event allocation failed");
   }
   *out = s;
+  return RTG_OK;
+}
+
+
+// Scheduling / measurement switches of ONE scene handle (none of them changes a bit of the result; every setting is
+// covered by test_every_kernel_variant_and_schedule_gives_the_same_bits).  The library itself reads no environment
+// variable for these: sweep tools and the test-suite set them through this call (capi.py forwards RTG_* variables).
+int rtg_scene_set_option(rtg_scene* s, const char* name, int value) {
+  if (!s || !name) return fail(RTG_ERR_INVALID, "null argument");
+  const std::string k(name);
+  const uint32_t u = (uint32_t)value;
+  if (k == "kernel") s->kernel_version = value;                 // 3 = ray pools (default), 1 = one lane per pixel
+  else if (k == "chunks") s->force_chunks = value;              // lean pool kernel: sample chunks per pixel, 0 = one sample per work item
+  else if (k == "lpt") s->lpt = value;                          // cost-ordered queue: 0 off, 1 block-major, 2 class-major (default)
+  else if (k == "lpt_phase1") s->lpt_phase1 = value;
+  else if (k == "lpt_deep") s->lpt_deep = value;
+  else if (k == "lpt_shift") s->lpt_shift = std::min(6, std::max(0, value));
+  else if (k == "ray_lds") s->ray_lds = value;
+  else if (k == "block") s->pool_threads = s->full_threads = value;
+  else if (k == "wg_per_cu") s->wg_per_cu = value;
+  else if (k == "verbose") s->verbose = value;                  // print launch geometry / schedule statistics to stderr
+  else if (k == "window") s->window = value;                    // full-feature kernel: records staged in LDS, -1 = automatic
+  else if (k == "box_leave") s->pool_tune.box_leave = s->full_tune.box_leave = u;
+  else if (k == "refill_min") s->pool_tune.refill_min = s->full_tune.refill_min = u;
+  else if (k == "gather_min") s->pool_tune.gather_min = s->full_tune.gather_min = u;
+  else if (k == "run_ahead") s->pool_tune.run_ahead = s->full_tune.run_ahead = u;
+  else if (k == "run_ahead_min") s->pool_tune.run_ahead_min = s->full_tune.run_ahead_min = u;
+  else if (k == "sphere_min") s->pool_tune.sphere_min = s->full_tune.sphere_min = u;
+  else return fail(RTG_ERR_INVALID, "rtg_scene_set_option: unknown option '" + k + "'");
   return RTG_OK;
 }
 
@@ -875,7 +854,7 @@ int rtg_par_cast_device(rtg_scene* s, const rtg_camera* camera, const rtg_params
     unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (count) HIP_TRY(hipMemcpy(h, s->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     stats->aabb_tests = h[0], stats->prim_tests = h[1], stats->shaded_hits = h[2], stats->rays = h[3], stats->draws = h[4];
-    if (count && getenv("RTG_VERBOSE") && s->lpt_desc.n_blocks && s->d_lpt) {  // cost classes of the last frame (class 0 = deepest)
+    if (count && s->verbose && s->lpt_desc.n_blocks && s->d_lpt) {  // cost classes of the last frame (class 0 = deepest)
       std::vector<uint32_t> ctl(LPT_CTL);
       HIP_TRY(hipMemcpy(ctl.data(), s->lpt_desc.ctl, LPT_CTL * sizeof(uint32_t), hipMemcpyDeviceToHost));
       std::string line;
@@ -883,7 +862,7 @@ int rtg_par_cast_device(rtg_scene* s, const rtg_camera* camera, const rtg_params
         if (ctl[c]) line += " " + std::to_string(c) + ":" + std::to_string(ctl[c]);
       fprintf(stderr, "[rtg] cost-ordered queue: %u of %u blocks filed, class:blocks%s\n", ctl[LPT_CLASSES], s->lpt_desc.n_blocks, line.c_str());
     }
-    if (count && getenv("RTG_VERBOSE")) {
+    if (count && s->verbose) {
       unsigned long long q[24];
       HIP_TRY(hipMemcpy(q, s->d_counters + 8, sizeof(q), hipMemcpyDeviceToHost));
       if (q[18]) {  // lean pool kernel: per-wave timeline, scaled so that the longest wave = the measured kernel time
@@ -896,14 +875,9 @@ int rtg_par_cast_device(rtg_scene* s, const rtg_camera* camera, const rtg_params
               "per pass: shade %.0f, gen|service %.0f, box %.0f, sphere %.0f ticks\n", 100 * q[8] / tt, 100 * q[9] / tt, 100 * q[10] / tt,
               100 * q[11] / tt, q[4] ? (double)q[8] / q[4] : 0., q[4] ? (double)q[9] / q[4] : 0., q[0] ? (double)q[10] / q[0] : 0.,
               q[2] ? (double)q[11] / q[2] : 0.);
-      if (s->kernel_version >= 3)
-        fprintf(stderr, "[rtg] pool schedule: box steps %llu (avg %.1f lanes), sphere passes %llu (avg %.1f lanes), shade passes %llu "
+      fprintf(stderr, "[rtg] pool schedule: box steps %llu (avg %.1f lanes), sphere passes %llu (avg %.1f lanes), shade passes %llu "
                 "(avg %.1f lanes), end passes %llu (avg %.1f lanes), refills %llu\n", q[0], q[0] ? (double)q[1] / q[0] : 0.0, q[2],
                 q[2] ? (double)q[3] / q[2] : 0.0, q[4], q[4] ? (double)q[5] / q[4] : 0.0, q[12], q[12] ? (double)q[13] / q[12] : 0.0, q[6]);
-      else
-      fprintf(stderr, "[rtg] schedule: box passes %llu (avg %.1f lanes), sphere passes %llu (avg %.1f lanes), regen passes %llu "
-              "(avg %.1f shade + %.1f gen lanes)\n", q[0], q[0] ? (double)q[1] / q[0] : 0.0, q[2], q[2] ? (double)q[3] / q[2] : 0.0,
-              q[4], q[4] ? (double)q[5] / q[4] : 0.0, q[4] ? (double)q[6] / q[4] : 0.0);
     }
   }
   return RTG_OK;

@@ -140,6 +140,7 @@ extern "C" {
     // ---- scene
     pub fn rtg_scene_create(b: *mut rtg_builder, world: *const rtg_id, n: usize, device: c_int, out: *mut *mut rtg_scene) -> c_int;
     pub fn rtg_scene_destroy(s: *mut rtg_scene);
+    pub fn rtg_scene_set_option(s: *mut rtg_scene, name: *const c_char, value: c_int) -> c_int;
     pub fn rtg_scene_info(s: *const rtg_scene, n_instructions: *mut u32, n_materials: *mut u32, n_textures: *mut u32, hbm_bytes: *mut u64) -> c_int;
 
     // ---- the hot path

@@ -250,3 +250,14 @@ def test_non_finite_exposure_is_refused(pkg, oracle):
         with pytest.raises(pkg.RtError) as e:
             sc.par_cast(cam, 8, 8, 1)
         assert e.value.code == -4, (e0, e1)
+
+
+def test_perlin_at_coordinates_beyond_i32(pkg, oracle):
+    """perlin.rs:53-55 `(p.x.floor() as i32 + di) & 255`: `as i32` saturates beyond 2^31 and i32::MAX + 1 wraps in a
+    release build.  A Perlin texture scaled by 1e10 puts every lookup there (the sanitizer leg watches this one)."""
+    S = pkg.scenes
+    b = oracle.builder()
+    world, cam, _ = S.book_final_scene(b, 16, 16, pkg.small_rng.SmallRng(0xDEADBEEF))   # installs Perlin tables
+    far = b.lambertian(b.perlin(1e10))
+    img = b.scene([b.translate(S.v(0.0, 0.0, 0.0), b.sphere(200.0, far))] + world).par_cast(cam, 16, 16, 2)
+    assert np.isfinite(img).all()

@@ -250,7 +250,6 @@ def test_albedo_range_routing_through_a_checker(pkg, gpu, oracle, lean):
 
 @pytest.mark.parametrize("env", [
     {"RTG_KERNEL": "1"},                       # one-lane-per-pixel baseline kernel
-    {"RTG_KERNEL": "2"},                       # persistent single-wave regeneration kernel
     {"RTG_KERNEL": "3", "RTG_CHUNKS": "1"},    # ray-pool kernel, a slot folds its own pixel
     {"RTG_KERNEL": "3", "RTG_CHUNKS": "3"},    # ray-pool kernel, 3 sample chunks per pixel + fold kernel
     {"RTG_KERNEL": "3"},                       # ray-pool kernel, automatic chunking
@@ -260,7 +259,7 @@ def test_albedo_range_routing_through_a_checker(pkg, gpu, oracle, lean):
 def test_every_kernel_variant_and_schedule_gives_the_same_bits(pkg, gpu, oracle, env, monkeypatch):
     """The schedule (kernel generation, chunking, thresholds) must never change a bit."""
     for k, v in env.items():
-        monkeypatch.setenv(k, v)   # read by rtg_scene_create
+        monkeypatch.setenv(k, v)   # capi.Scene forwards RTG_* to rtg_scene_set_option
     for name, nx, ny, ns in (("book1", 72, 40, 7), ("book1_list", 24, 16, 4)):
         sg, cam_g, _, _, _ = build_case(pkg, gpu, name, nx, ny)
         so, cam_o, _, _, _ = build_case(pkg, oracle, name, nx, ny)
@@ -285,7 +284,7 @@ def test_cost_ordered_queue_never_changes_a_bit(pkg, gpu, oracle, env, monkeypat
     RTG_LPT_PHASE1 forces it on at a size the oracle renders in a second.  Lean and full-feature kernel, one rank
     and a shard."""
     for k, v in env.items():
-        monkeypatch.setenv(k, v)   # read by rtg_scene_create
+        monkeypatch.setenv(k, v)   # capi.Scene forwards RTG_* to rtg_scene_set_option
     for name, nx, ny, ns in (("book1", 176, 112, 12), ("cornell", 144, 128, 12), ("book2", 160, 112, 9)):
         sg, cam_g, _, _, _ = build_case(pkg, gpu, name, nx, ny)
         so, cam_o, _, _, _ = build_case(pkg, oracle, name, nx, ny)
