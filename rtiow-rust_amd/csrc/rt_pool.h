@@ -23,6 +23,8 @@
 // Scheduling never changes results: every (pixel, sample, event) has its own RNG stream and a pixel's
 // samples are folded in sample order.
 #pragma once
+#include <type_traits>
+
 #include "rt_trace.h"
 
 namespace rtg {
@@ -78,7 +80,7 @@ enum PoolField : uint32_t {
 constexpr uint32_t LPT_BLOCK = 256;   // pixels per cost block = WORK_BLOCK
 constexpr uint32_t LPT_CLASSES = 64;  // one per lane
 constexpr uint32_t LPT_CTL = 80;      // count[64], [64] = blocks filed so far
-struct LptQueue {       // descriptor (passed by value inside ChunkMode); cost / ctl / list live in device memory
+struct LptQueue {       // lives in device memory: the kernels touch it once per 256-item reservation
   uint32_t* cost;       // [n_blocks] scatter events per block during phase 1
   uint32_t* ctl;        // [LPT_CTL]
   uint32_t* list;       // [LPT_CLASSES][n_blocks] blocks of each class, in filing order
@@ -95,7 +97,7 @@ struct ChunkMode {
   uint32_t chunk;      // samples per work item
   uint32_t n_chunks;   // work items per pixel
   uint32_t pix_work;   // pixel work items of this rank (tiles x tile area, incl. out-of-image padding)
-  // Cost-ordered queue ("longest processing time first"), lpt_on != 0.  The end of a frame is a chain
+  // Cost-ordered queue ("longest processing time first"), lpt != null.  The end of a frame is a chain
   // problem, not a throughput problem: a path that runs into the bounce cap (glass: ~0.2 % of book-1's
   // samples) needs 51 dependent traverse + scatter generations, and the ones that START late finish
   // ~1.2 ms after the queue is empty (measured: fixed cost per C2 launch 1.69 ms at cap 50, 0.46 ms at
@@ -104,8 +106,8 @@ struct ChunkMode {
   // logarithmic cost classes; the remaining chunks run block-major, classes in descending cost order:
   // long-path-prone blocks first, sky last.  Order never changes results (per-event RNG streams,
   // ordered fold).
-  LptQueue lpt;          // by value: a kernel argument, so a launch never reads a descriptor another launch may rewrite
-  uint32_t lpt_on;       // 0: natural order throughout
+  const LptQueue* lpt;   // descriptor in device memory (a by-value copy inside the kernel arguments cost 19 more SGPR spills and
+                         // 8 % of a C2 launch); written on the LAUNCH STREAM by write_lpt_descriptor, so launches stay ordered
   uint32_t lpt_samples;  // samples [0, lpt_samples) of every pixel belong to phase 1 (0 = off)
   uint32_t lpt_deep;     // a scatter event counts towards its block's cost from this bounce on
 };
@@ -118,7 +120,7 @@ RT_DEV void lpt_count(const ChunkMode& cm, bool on, uint32_t blk) {
   while (todo) {
     const uint32_t b0 = __builtin_amdgcn_readlane(blk, (uint32_t)__builtin_ctzll(todo));
     const uint64_t same = __builtin_amdgcn_ballot_w64(on && blk == b0);
-    if (on && blk == b0 && lane_rank(same) == 0u) atomicAdd(&cm.lpt.cost[b0], (uint32_t)__builtin_popcountll(same));
+    if (on && blk == b0 && lane_rank(same) == 0u) atomicAdd(&cm.lpt->cost[b0], (uint32_t)__builtin_popcountll(same));
     todo &= ~same;
   }
 }
@@ -126,7 +128,7 @@ RT_DEV void lpt_count(const ChunkMode& cm, bool on, uint32_t blk) {
 // A wave reserved work items [base, base + WORK_BLOCK): they all belong to one chunk and one 256-pixel
 // block (pix_work is a multiple of 256).  Returns the chunk; item w is pixel work index w + delta.
 RT_DEV uint32_t lpt_reservation(const ChunkMode& cm, uint32_t base, uint32_t lane, uint32_t& delta, bool& ready) {
-  const LptQueue* q = cm.lpt_on ? &cm.lpt : nullptr;
+  const LptQueue* q = cm.lpt;
   if (q == nullptr || base < q->phase2_base) {
     const uint32_t c = base / cm.pix_work;
     delta = 0u - c * cm.pix_work;
@@ -176,7 +178,15 @@ RT_DEV uint32_t lpt_reservation(const ChunkMode& cm, uint32_t base, uint32_t lan
 #define RT_NT_SCRATCH 1
 #endif
 #if RT_NT_SCRATCH
+#ifndef RT_SCRATCH_X3
+#define RT_SCRATCH_X3 1
+#endif
+#if RT_SCRATCH_X3
+typedef float f32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+#define RT_SCRATCH_STORE(p_, v_) __builtin_nontemporal_store(f32x3_a4{(v_).x, (v_).y, (v_).z}, reinterpret_cast<f32x3_a4*>(p_))  // one global_store_dwordx3
+#else
 #define RT_SCRATCH_STORE(p_, v_) (__builtin_nontemporal_store((v_).x, (p_)), __builtin_nontemporal_store((v_).y, (p_) + 1), __builtin_nontemporal_store((v_).z, (p_) + 2))
+#endif
 #define RT_SCRATCH_LOAD(p_) __builtin_nontemporal_load(p_)
 #else
 #define RT_SCRATCH_STORE(p_, v_) ((p_)[0] = (v_).x, (p_)[1] = (v_).y, (p_)[2] = (v_).z)
@@ -192,6 +202,9 @@ RT_DEV uint32_t pixel_to_work(const DevParams& P, uint32_t x, uint32_t row) {
   uint32_t b = (ly >> 3) * (P.tile_w >> 3) + (lx >> 3);
   return k * (P.tile_w * P.tile_h) + b * 64u + (ly & 7u) * 8u + (lx & 7u);
 }
+
+// stream-ordered update of the descriptor (a kernel argument by value: no host buffer has to outlive the call)
+__global__ void write_lpt_descriptor(LptQueue* dst, LptQueue v) { *dst = v; }
 
 // second pass of the chunk mode: ordered fold of the per-sample colours (vec3.rs:195-203, lib.rs:374)
 __global__ void fold_samples_kernel(DevParams P, ChunkMode cm, float* __restrict__ out) {
@@ -218,30 +231,46 @@ struct PoolTuning {
   uint32_t gather_min;   // full-feature kernel: lanes waiting at an F_GATHER record before they are released together
 };
 
-// LDS image of the program (staged variant): one 56-byte record per instruction, pc = 56 r.
-//   BOX     dw0-5  (min.x, max.x) (min.y, max.y) (min.z, max.z)     the pairs a ray with 1/d >= 0 wants
-//           dw6-11 (max.x, min.x) (max.y, min.y) (max.z, min.z)     ... and one with 1/d < 0
-//           dw12 skip pc   dw13 op/flags | LDS_BOX_BIT
-//   others  dw0-3 = lo, dw4-7 = hi, dw13 = op/flags
-// pc is the record's absolute LDS address (a step forms no base + offset sum); "is this a BOX" is the
-// sign bit of the flag word (one compare, no mask).
+// LDS image of the program (staged variant): variable-size records, pc = the record's absolute LDS address (a step forms
+// no base + offset sum); every record starts with the dword pair a traversal step needs first:
+//   BOX     56 B  dw0 skip pc (absolute)   dw1 op/flags | LDS_BOX_BIT
+//                 dw2-7  (min.x, max.x) (min.y, max.y) (min.z, max.z)     the pairs a ray with 1/d >= 0 wants
+//                 dw8-13 (max.x, min.x) (max.y, min.y) (max.z, min.z)     ... and one with 1/d < 0
+//   SPHERE  24 B  dw0 material index       dw1 op/flags (F_TRANSLATE, F_FLIP, material kind)    dw2-5 offset.xyz, radius
+//   END      8 B  dw0 -                    dw1 OP_END      (+ 56 B of padding: a step's plane loads stay inside the image)
+// A BOX that passes continues at pc + 56 (its left child, or its leaf's SPHERE), a SPHERE at pc + 24; "is this a BOX" is
+// the sign bit of the flag word (one compare, no mask).  book-1: 969 x 56 + 485 x 24 + 64 = 66.0 KB (81.5 KB with
+// uniform 56-byte records): the 15.5 KB pay for the slots' (best, best_pc) in LDS.
 // Aabb::hit swaps (t0, t1) when 1/d < 0 (aabb.rs:20-23).  A lane reads ITS (near plane, far plane) pair
 // per axis with one ALIGNED 8-byte load (ds_read_b64: 2 LDS cycles per wave, against 4 for the
-// ds_read2_b32 an unaligned pair needs -- the box loop runs the LDS pipe at ~80 %); the offset is
-// fixed per ray, so the swap costs no instruction per step.
-constexpr uint32_t LDS_REC = 56;
+// ds_read2_b32 an unaligned pair needs); the offset is fixed per ray, so the swap costs no instruction per step.
+constexpr uint32_t LDS_BOX_BYTES = 56, LDS_SPHERE_BYTES = 24, LDS_END_BYTES = 8 + 56;
 constexpr uint32_t LDS_BOX_BIT = 0x80000000u;
 typedef __attribute__((address_space(3))) const char* lds_cptr;
 
-// dynamic LDS bytes for a workgroup of `waves` waves.  The path slots live in a per-wave SoA region of
-// global memory (L2-resident; a field access of 64 lanes touches at most 4 cache lines), which leaves
-// LDS to the program and lets 16 waves share a CU.
-inline size_t pool_lds_bytes(uint32_t n_prog, uint32_t n_mat, uint32_t waves, bool stage_program, bool ray_lds) {
-  size_t b = stage_program ? ((size_t)n_prog * LDS_REC + (size_t)n_mat * 16) : 0;  // records + (albedo | emission, param) per material
+// byte offset of every record inside the image (host side, at scene creation); returns the image size (multiple of 16).
+// Only lean programs (BOX / SPHERE / END) have an image.
+inline uint32_t lds_image_offsets(const uint32_t* op_words, size_t n, uint32_t* off) {
+  uint32_t at = 0;
+  for (size_t i = 0; i < n; i++) {
+    off[i] = at;
+    const uint32_t op = op_words[i] & 0xffu;
+    at += op == OP_BOX ? LDS_BOX_BYTES : (op == OP_SPHERE ? LDS_SPHERE_BYTES : LDS_END_BYTES);
+  }
+  return (at + 15u) & ~15u;
+}
+
+// dynamic LDS bytes for a workgroup of `waves` waves: [program image | materials] [T-, S-, E-list] [slot rays] [slot best]
+// [slot best_pc].  The HOT slot fields -- the ray (o, d): written by the SCATTER and END passes, read by the refill and the
+// SCATTER pass; (best, best_pc): written when a ray finishes, read by the pass that shades it -- live in LDS (`hot_lds`,
+// when the program leaves room); the cold ones (strength, bounces, sample, pixel) in a per-wave SoA region of global memory
+// sized to stay in the L2s.
+inline size_t pool_lds_bytes(uint32_t image_bytes, uint32_t n_mat, uint32_t waves, bool stage_program, bool hot_lds) {
+  size_t b = stage_program ? ((size_t)image_bytes + (size_t)n_mat * 16) : 0;  // records + (albedo | emission, param) per material
   b += (size_t)waves * POOL * 3 * 2;  // T-, S- and E-list (u16 slot ids)
   b = (b + 15) & ~(size_t)15;
-  if (ray_lds) b += (size_t)waves * POOL * 6 * sizeof(float);  // the slots' rays (o, d)
-  return b;
+  if (hot_lds) b += (size_t)waves * POOL * (6 * sizeof(float) + sizeof(float) + (stage_program ? 2 : 4));
+  return (b + 15) & ~(size_t)15;
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -285,10 +314,9 @@ RT_DEV uint4 fetch_hi_global(const DevScene& sc, uint32_t idx) {  // byte-offset
 // Each pass type runs 64 lanes wide over slots of ITS class, so a wave no longer issues the union of
 // the scatter code and the camera code for every batch of finished rays.  The class of a hit is read
 // from the winning SPHERE record (the flattener copies the material kind into its flag word).
-// RAY_LDS: the six most-travelled slot fields -- the ray (o, d): written by the SCATTER and END passes,
-// read by the refill and the SCATTER pass -- live in LDS when the program leaves room; the other
-// fields stay in the global SoA region.
-template <bool USE_LDS, bool COUNT, bool RAY_LDS>
+// HOT_LDS: the hot slot fields -- the ray (o, d) and (best, best_pc), see pool_lds_bytes -- live in LDS when the
+// program leaves room; the cold fields stay in the global SoA region.
+template <bool USE_LDS, bool COUNT, bool HOT_LDS>
 __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void render_lean_pool(
     DevScene sc, DevCamera cam, DevParams P, float* __restrict__ out, uint32_t total_work, uint32_t* __restrict__ queue,
     unsigned long long* counters, PoolTuning tune, ChunkMode cm, uint32_t* __restrict__ g_slots) {
@@ -297,44 +325,73 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
   // Program counters are BYTE offsets: REC r.  Staged: into the LDS image above (a step needs no shift,
   // BOX skip pointers are stored pre-multiplied).  Not staged (program larger than LDS): REC = 16 and
   // (lo, hi) come from global memory.
-  constexpr uint32_t REC = USE_LDS ? LDS_REC : 16u;
-  const uint32_t staged = USE_LDS ? LDS_REC * n_prog + 16u * sc.n_mat : 0u;  // bytes
+  constexpr uint32_t REC_BOX = USE_LDS ? LDS_BOX_BYTES : 16u, REC_SPHERE = USE_LDS ? LDS_SPHERE_BYTES : 16u;
+  const uint32_t image = USE_LDS ? sc.lds_image_bytes : 0u;
+  const uint32_t staged = USE_LDS ? image + 16u * sc.n_mat : 0u;  // bytes
   uint32_t* s_words = reinterpret_cast<uint32_t*>(s_mem);
   const uint32_t pc0 = USE_LDS ? (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)s_mem : 0u;  // pc of record 0
   if (USE_LDS) {
     for (uint32_t i = threadIdx.x; i < n_prog; i += blockDim.x) {
       const uint4 l = sc.lo[i], h = sc.hi[i];
-      uint32_t* r = s_words + 14u * i;
-      r[0] = l.x, r[1] = l.y, r[2] = l.z, r[3] = l.w, r[4] = h.x, r[5] = h.y, r[6] = h.z, r[7] = h.w;
-      r[12] = 0u, r[13] = h.w;
-      if ((h.w & 0xffu) == OP_BOX) {  // lo = (min.x, max.x, min.y, max.y), hi = (min.z, max.z, skip, flags)
-        r[6] = l.y, r[7] = l.x, r[8] = l.w, r[9] = l.z, r[10] = h.y, r[11] = h.x;
-        r[12] = pc0 + h.z * LDS_REC, r[13] = h.w | LDS_BOX_BIT;
+      uint32_t* r = s_words + (sc.lds_off[i] >> 2);
+      const uint32_t op = h.w & 0xffu;
+      if (op == OP_BOX) {  // lo = (min.x, max.x, min.y, max.y), hi = (min.z, max.z, skip, flags)
+        r[0] = pc0 + sc.lds_off[h.z], r[1] = h.w | LDS_BOX_BIT;
+        r[2] = l.x, r[3] = l.y, r[4] = l.z, r[5] = l.w, r[6] = h.x, r[7] = h.y;
+        r[8] = l.y, r[9] = l.x, r[10] = l.w, r[11] = l.z, r[12] = h.y, r[13] = h.x;
+      } else if (op == OP_SPHERE) {  // lo = (offset.xyz, radius), hi = (-, -, material, flags)
+        r[0] = h.z, r[1] = h.w, r[2] = l.x, r[3] = l.y, r[4] = l.z, r[5] = l.w;
+      } else {  // END + padding
+        r[0] = 0u, r[1] = h.w;
+        for (uint32_t k = 2; k < LDS_END_BYTES / 4u; k++) r[k] = 0u;
       }
     }
     for (uint32_t i = threadIdx.x; i < sc.n_mat; i += blockDim.x) {
       const uint4 m = sc.mat[2u * i];
-      uint32_t* r = s_words + 14u * n_prog + 4u * i;
+      uint32_t* r = s_words + (image >> 2) + 4u * i;
       r[0] = m.x, r[1] = m.y, r[2] = m.z, r[3] = m.w;
     }
   }
-#define RT_FETCH_LO(pc_) (USE_LDS ? lds_u4(pc_) : sc.lo[(pc_) >> 4])
-#define RT_FETCH_HI(pc_) (USE_LDS ? lds_u4((pc_) + 16u) : fetch_hi_global(sc, (pc_) >> 4))
-#define RT_FETCH_MATLO(i_) (USE_LDS ? lds_u4(pc0 + LDS_REC * n_prog + 16u * (i_)) : sc.mat[2u * (i_)])
+  // a SPHERE record as (offset.xyz, radius), its flag word and its material index
+#define RT_SPHERE_GEOM(pc_) (USE_LDS ? lds_u4((pc_) + 8u) : sc.lo[(pc_) >> 4])
+#define RT_SPHERE_FLAGS(pc_) (USE_LDS ? RT_AS3(uint32_t, (pc_) + 4u) : sc.hi[(pc_) >> 4].w)
+#define RT_SPHERE_MAT(pc_) (USE_LDS ? RT_AS3(uint32_t, (pc_)) : sc.hi[(pc_) >> 4].z)
+#define RT_FETCH_MATLO(i_) (USE_LDS ? lds_u4(pc0 + image + 16u * (i_)) : sc.mat[2u * (i_)])
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, n_waves = blockDim.x >> 6;
   uint32_t* slot = g_slots + ((size_t)blockIdx.x * n_waves + wave) * (POOL * POOL_FIELDS);
   float* slotf = reinterpret_cast<float*>(slot);
   uint16_t* tlist = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(s_mem) + staged) + wave * (3u * POOL);
   uint16_t* slist = tlist + POOL;
   uint16_t* elist = slist + POOL;
-  float* lds_ray = reinterpret_cast<float*>(reinterpret_cast<char*>(s_mem) + (((size_t)staged + n_waves * POOL * 6u + 15u) & ~(size_t)15u)) +
-                   (size_t)wave * (POOL * 6u);
+  char* hot_base = reinterpret_cast<char*>(s_mem) + (((size_t)staged + n_waves * POOL * 6u + 15u) & ~(size_t)15u);
+  float* lds_ray = reinterpret_cast<float*>(hot_base) + (size_t)wave * (POOL * 6u);
+  float* lds_best = reinterpret_cast<float*>(hot_base) + (size_t)n_waves * (POOL * 6u) + (size_t)wave * POOL;
+  // best_pc in LDS: staged programs fit 16 bits ((pc - pc0) / 8; the three markers keep their low 16 bits), others 32
+  typedef typename std::conditional<USE_LDS, uint16_t, uint32_t>::type bpc_t;
+  bpc_t* lds_bpc = reinterpret_cast<bpc_t*>(reinterpret_cast<float*>(hot_base) + (size_t)n_waves * (POOL * 7u)) + (size_t)wave * POOL;
 #define SLOT_U(f_, j_) slot[(f_)*POOL + (j_)]
 #define SLOT_F(f_, j_) slotf[(f_)*POOL + (j_)]
-#define RAY_F(f_, j_) (*(RAY_LDS ? &lds_ray[(f_)*POOL + (j_)] : &slotf[(f_)*POOL + (j_)]))
+#define RAY_F(f_, j_) (*(HOT_LDS ? &lds_ray[(f_)*POOL + (j_)] : &slotf[(f_)*POOL + (j_)]))
+#ifndef RT_HOT_BEST
+#define RT_HOT_BEST 1  // 0: (best, best_pc) stay in the global slot rows even when the rays are in LDS
+#endif
+  constexpr bool BEST_LDS = HOT_LDS && RT_HOT_BEST;
+#define BEST_F(j_) (*(BEST_LDS ? &lds_best[(j_)] : &slotf[PF_BEST * POOL + (j_)]))
+  // (the markers NO_HIT / SLOT_NEED_PIXEL / SLOT_ENDED are 0xffffffff / ...fe / ...fd: distinct in 16 bits, above any record)
+  auto put_bpc = [&](uint32_t j, uint32_t v) {
+    if (!BEST_LDS) slot[PF_BEST_PC * POOL + j] = v;
+    else if (USE_LDS) lds_bpc[j] = (bpc_t)(v >= SLOT_ENDED ? v : (v - pc0) >> 3);
+    else lds_bpc[j] = (bpc_t)v;
+  };
+  auto get_bpc = [&](uint32_t j) -> uint32_t {
+    if (!BEST_LDS) return slot[PF_BEST_PC * POOL + j];
+    const uint32_t v = lds_bpc[j];
+    if (!USE_LDS) return v;
+    return v >= (SLOT_ENDED & 0xffffu) ? (v | 0xffff0000u) : pc0 + (v << 3);
+  };
   // all slots start as "need a work item", all on the E-list
   for (uint32_t j = lane; j < POOL; j += 64u) {
-    SLOT_U(PF_BEST_PC, j) = SLOT_NEED_PIXEL;
+    put_bpc(j, SLOT_NEED_PIXEL);
     elist[j] = (uint16_t)j;
   }
   __syncthreads();  // program staged, pools initialised (the only workgroup barrier)
@@ -368,10 +425,10 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
   // load the record at pc into (cx, cy, cz, c_skip, c_flags)
 #define RT_LOAD_REC() \
         if (USE_LDS) { \
+          const u32x2 sf_ = RT_AS3(u32x2, pc); \
           cx = RT_AS3(f32x2, pc + sgn_x); \
           cy = RT_AS3(f32x2, pc + sgn_y); \
           cz = RT_AS3(f32x2, pc + sgn_z); \
-          const u32x2 sf_ = RT_AS3(u32x2, pc + 48u); \
           c_skip = sf_.x, c_flags = sf_.y; \
         } else { \
           const uint4 l_ = sc.lo[pc >> 4], h_ = sc.hi[pc >> 4]; \
@@ -398,7 +455,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           RT_BOX_T(tz, cz, o.z, inv.z); \
           float start = rs_max(t_near, rs_max(rs_max(tx.x, ty.x), tz.x)); \
           float end = rs_min(best, rs_min(rs_min(tx.y, ty.y), tz.y)); \
-          pc = (end > start) ? pc + REC : c_skip; \
+          pc = (end > start) ? pc + REC_BOX : c_skip; \
           RT_LOAD_REC(); \
         }
   for (;;) {
@@ -416,8 +473,8 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
         const bool to_s = fin && !to_e;
         const uint64_t m_e = __builtin_amdgcn_ballot_w64(to_e), m_s = __builtin_amdgcn_ballot_w64(to_s);
         if (fin) {
-          SLOT_F(PF_BEST, my_slot) = best;
-          SLOT_U(PF_BEST_PC, my_slot) = best_pc;
+          BEST_F(my_slot) = best;
+          put_bpc(my_slot, best_pc);
           if (to_e) elist[e_count + lane_rank(m_e)] = (uint16_t)my_slot;
           else slist[s_count + lane_rank(m_s)] = (uint16_t)my_slot;
           have_ray = false;
@@ -437,28 +494,31 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
         uint32_t j = 0, lpt_blk = 0;
         if (lane < take) {
           j = slist[s_count + lane];
-          const uint32_t bpc = SLOT_U(PF_BEST_PC, j);
+          const uint32_t bpc = get_bpc(j);
           V3 so = mk(RAY_F(PF_O, j), RAY_F(PF_O + 1, j), RAY_F(PF_O + 2, j));
           V3 sd = mk(RAY_F(PF_D, j), RAY_F(PF_D + 1, j), RAY_F(PF_D + 2, j));
-          V3 strength = mk(SLOT_F(PF_STRENGTH, j), SLOT_F(PF_STRENGTH + 1, j), SLOT_F(PF_STRENGTH + 2, j));
           uint32_t bounces = SLOT_U(PF_BOUNCES, j);
+          // the strength row is only valid from the first scatter on: a fresh path carries (1, 1, 1) (lib.rs:63) implicitly
+          V3 strength = mk(SLOT_F(PF_STRENGTH, j), SLOT_F(PF_STRENGTH + 1, j), SLOT_F(PF_STRENGTH + 2, j));
+          if (bounces == 0u) strength = splat(1.f);
           const uint32_t s = SLOT_U(PF_SAMPLE, j), xy = SLOT_U(PF_XY, j);
-          const float hb = SLOT_F(PF_BEST, j);
+          const float hb = BEST_F(j);
           // ---------------- color() loop body, lib.rs:73-97, for a hit on a scattering material ----------
           SampleRng rng;
           rng.init(seed, (P.ny - 1u - (xy >> 16)) * P.nx + (xy & 0xffffu), s);
           rng.set_event(bounces + 1u);
           if (COUNT) cnt.shaded++;
-          const uint4 plo = RT_FETCH_LO(bpc), phi = RT_FETCH_HI(bpc);
+          const uint4 plo = RT_SPHERE_GEOM(bpc);
+          const uint32_t pflags = RT_SPHERE_FLAGS(bpc);
           V3 off = mk(u2f(plo.x), u2f(plo.y), u2f(plo.z));
           V3 lo_o = so;
-          if (phi.w & F_TRANSLATE) lo_o = vsub(so, off);       // object.rs:275-278
+          if (pflags & F_TRANSLATE) lo_o = vsub(so, off);      // object.rs:275-278
           V3 hp = vadd(lo_o, smul(hb, sd));                    // ray.rs:15
           V3 hn = sdiv(hp, u2f(plo.w));                        // object.rs:104
-          if (phi.w & F_TRANSLATE) hp = vadd(hp, off);         // object.rs:279-282
-          if (phi.w & F_FLIP) hn = vneg(hn);                   // object.rs:249-252
-          const uint4 mlo = RT_FETCH_MATLO(phi.z);
-          const uint32_t kind = (phi.w >> F_MATKIND_SHIFT) & 7u;  // the flattener's copy of the material kind
+          if (pflags & F_TRANSLATE) hp = vadd(hp, off);        // object.rs:279-282
+          if (pflags & F_FLIP) hn = vneg(hn);                  // object.rs:249-252
+          const uint4 mlo = RT_FETCH_MATLO(RT_SPHERE_MAT(bpc));
+          const uint32_t kind = (pflags >> F_MATKIND_SHIFT) & 7u;  // the flattener's copy of the material kind
           const float param = u2f(mlo.w);
           const V3 mcol = mk(u2f(mlo.x), u2f(mlo.y), u2f(mlo.z));
           // lib.rs:76 with emitted = 0 (material.rs:126): accum stays +0, see PoolField
@@ -524,7 +584,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
             if (COUNT) cnt.rays++;
           } else {  // both early returns of color() yield accum (lib.rs:90,94): the END pass books it
             ended = true;
-            SLOT_U(PF_BEST_PC, j) = SLOT_ENDED;
+            put_bpc(j, SLOT_ENDED);
           }
         }
         if (cm.lpt_samples) lpt_count(cm, lpt_on, lpt_blk);
@@ -545,7 +605,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
         V3 col = mk(0.f, 0.f, 0.f);
         if (lane < take) {
           j = elist[e_count + lane];
-          const uint32_t bpc = SLOT_U(PF_BEST_PC, j);
+          const uint32_t bpc = get_bpc(j);
           if (bpc == SLOT_NEED_PIXEL) {
             st = ST_NEED_PIXEL;
           } else {
@@ -558,9 +618,9 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
               result = accum;  // SLOT_ENDED: color() already returned accum
               if (bpc != SLOT_ENDED) {  // DiffuseLight hit: lib.rs:76 then scatter() == None (material.rs:108)
                 if (COUNT) cnt.shaded++;
-                const V3 strength = mk(SLOT_F(PF_STRENGTH, j), SLOT_F(PF_STRENGTH + 1, j), SLOT_F(PF_STRENGTH + 2, j));
-                const uint4 phi = RT_FETCH_HI(bpc);
-                const uint4 mlo = RT_FETCH_MATLO(phi.z);
+                V3 strength = mk(SLOT_F(PF_STRENGTH, j), SLOT_F(PF_STRENGTH + 1, j), SLOT_F(PF_STRENGTH + 2, j));
+                if (SLOT_U(PF_BOUNCES, j) == 0u) strength = splat(1.f);  // the camera ray hit the light: lib.rs:63
+                const uint4 mlo = RT_FETCH_MATLO(RT_SPHERE_MAT(bpc));
                 const V3 emitted = smul(u2f(mlo.w), mk(u2f(mlo.x), u2f(mlo.y), u2f(mlo.z)));  // material.rs:120-128
                 result = vadd(accum, vmul(strength, emitted));
               }
@@ -637,7 +697,6 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           if (COUNT) total_draws += rng.draws, cnt.rays++;
           RAY_F(PF_O, j) = so.x, RAY_F(PF_O + 1, j) = so.y, RAY_F(PF_O + 2, j) = so.z;
           RAY_F(PF_D, j) = sd.x, RAY_F(PF_D + 1, j) = sd.y, RAY_F(PF_D + 2, j) = sd.z;
-          SLOT_F(PF_STRENGTH, j) = 1.f, SLOT_F(PF_STRENGTH + 1, j) = 1.f, SLOT_F(PF_STRENGTH + 2, j) = 1.f;
           if (!cm.scratch) SLOT_F(PF_COL, j) = col.x, SLOT_F(PF_COL + 1, j) = col.y, SLOT_F(PF_COL + 2, j) = col.z;
           SLOT_U(PF_BOUNCES, j) = 0u, SLOT_U(PF_SAMPLE, j) = s;
           SLOT_U(PF_XY, j) = x | (row << 16);
@@ -661,7 +720,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
             o = mk(RAY_F(PF_O, my_slot), RAY_F(PF_O + 1, my_slot), RAY_F(PF_O + 2, my_slot));
             d = mk(RAY_F(PF_D, my_slot), RAY_F(PF_D + 1, my_slot), RAY_F(PF_D + 2, my_slot));
             inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);  // aabb.rs:17
-            sgn_x = inv.x < 0.f ? 24u : 0u, sgn_y = inv.y < 0.f ? 32u : 8u, sgn_z = inv.z < 0.f ? 40u : 16u;  // aabb.rs:20-23
+            sgn_x = inv.x < 0.f ? 32u : 8u, sgn_y = inv.y < 0.f ? 40u : 16u, sgn_z = inv.z < 0.f ? 48u : 24u;  // aabb.rs:20-23
             pc = pc0, best = F32_MAX, best_pc = NO_HIT, best_flags = 0;
             RT_LOAD_REC();
             have_ray = true;
@@ -709,7 +768,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
       if (COUNT) n_sph_it++, n_sph_lanes += (uint32_t)__builtin_popcountll(b_sph), t_mark = RT_TICK();
       if (op == OP_SPHERE) {  // Sphere::hit, object.rs:84-111 (+ Translate :275)
         if (COUNT) cnt.prim++;
-        const uint4 slo = RT_FETCH_LO(pc);  // (offset.xyz, radius)
+        const uint4 slo = RT_SPHERE_GEOM(pc);  // (offset.xyz, radius)
         V3 lo_o = o;
         if (c_flags & F_TRANSLATE) lo_o = vsub(o, mk(u2f(slo.x), u2f(slo.y), u2f(slo.z)));
         float t;
@@ -718,7 +777,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           best_pc = pc;
           best_flags = c_flags;
         }
-        pc += REC;
+        pc += REC_SPHERE;
         RT_LOAD_REC();
       }
       if (COUNT) t_sph += RT_TICK() - t_mark;
@@ -755,9 +814,11 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
 #undef RT_BOX_T
 #undef RT_LOAD_REC
 #undef RT_IS_BOX
-#undef RT_FETCH_LO
-#undef RT_FETCH_HI
+#undef RT_SPHERE_GEOM
+#undef RT_SPHERE_FLAGS
+#undef RT_SPHERE_MAT
 #undef RT_FETCH_MATLO
+#undef BEST_F
 #undef SLOT_U
 #undef SLOT_F
 #undef RAY_F

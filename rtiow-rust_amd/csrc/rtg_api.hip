@@ -156,7 +156,7 @@ struct rtg_scene {
   uint32_t features = 0;
   uint32_t n_prog = 0, n_mat = 0, n_tex = 0;
   uint64_t bytes = 0;
-  void* buffers[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  void* buffers[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   unsigned long long* d_counters = nullptr;  // [0..4] N/P/H/rays/draws, [7] = work-queue head (persistent kernel)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t own_stream = nullptr;  // rtg_par_cast_multi: this scene's launch stream (created on first use)
@@ -240,9 +240,10 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
   hipError_t e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream);  // re-initialise every call
   if (e != hipSuccess) return e;
   const size_t lds_limit = 160 * 1024;
-  bool use_lds = pool_lds_bytes(s->n_prog, s->n_mat, waves, true, false) <= lds_limit;
-  bool ray_lds = s->ray_lds && pool_lds_bytes(s->n_prog, s->n_mat, waves, use_lds, true) <= lds_limit;
-  size_t lds = pool_lds_bytes(s->n_prog, s->n_mat, waves, use_lds, ray_lds);
+  const uint32_t image = s->dev.lds_image_bytes;
+  bool use_lds = image != 0 && pool_lds_bytes(image, s->n_mat, waves, true, false) <= lds_limit;
+  bool ray_lds = s->ray_lds && pool_lds_bytes(image, s->n_mat, waves, use_lds, true) <= lds_limit;
+  size_t lds = pool_lds_bytes(image, s->n_mat, waves, use_lds, ray_lds);
   void (*kernel)(DevScene, DevCamera, DevParams, float*, uint32_t, uint32_t*, unsigned long long*, PoolTuning, ChunkMode,
                  uint32_t*);
   if (ray_lds) kernel = use_lds ? render_lean_pool<true, COUNT, true> : render_lean_pool<false, COUNT, true>;
@@ -261,7 +262,7 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
   e = setup_lpt(s, cm, (uint64_t)grid * waves * POOL, stream);
   if (e != hipSuccess) return e;
   if (s->verbose)
-    fprintf(stderr, "[rtg] pool: grid %u x %d threads, %d WG/CU, lds %zu B (program staged: %d, rays in LDS: %d), %u chunk(s) of %u samples, cost-ordered queue after %u chunk(s)\n", grid,
+    fprintf(stderr, "[rtg] pool: grid %u x %d threads, %d WG/CU, lds %zu B (program staged: %d, hot slot fields in LDS: %d), %u chunk(s) of %u samples, cost-ordered queue after %u chunk(s)\n", grid,
             bt, per_cu, lds, (int)use_lds, (int)ray_lds, cm.n_chunks, cm.chunk, cm.lpt_samples / (cm.chunk ? cm.chunk : 1u));
   {
     size_t need = (size_t)grid * waves * POOL * POOL_FIELDS * sizeof(uint32_t);
@@ -296,8 +297,7 @@ static hipError_t grow(void** buf, size_t* have, size_t need) {
 // Cost-ordered work queue (rt_pool.h, ChunkMode): enabled when the frame has enough chunks for a measuring
 // phase and enough blocks to order; the buffers are re-zeroed on the launch stream every call.
 static hipError_t setup_lpt(rtg_scene* s, ChunkMode& cm, uint64_t capacity, hipStream_t stream) {
-  memset(&cm.lpt, 0, sizeof(cm.lpt));
-  cm.lpt_on = 0, cm.lpt_samples = 0, cm.lpt_deep = 0;
+  cm.lpt = nullptr, cm.lpt_samples = 0, cm.lpt_deep = 0;
   const uint32_t n_blocks = cm.pix_work / LPT_BLOCK;
   if (!s->lpt || !cm.scratch || cm.n_chunks < 6 || n_blocks < 64 || n_blocks > 65536 || cm.pix_work % LPT_BLOCK) return hipSuccess;
   // Phase 1 must outlast the first fill of the pools (`capacity` paths in flight) by enough for the
@@ -305,20 +305,26 @@ static hipError_t setup_lpt(rtg_scene* s, ChunkMode& cm, uint64_t capacity, hipS
   uint32_t phase1 = std::max<uint32_t>(std::min(8u, std::max(2u, cm.n_chunks / 8u)), (uint32_t)((2 * capacity + cm.pix_work - 1) / cm.pix_work));
   if (s->lpt_phase1 > 0) phase1 = (uint32_t)s->lpt_phase1;
   if (phase1 < 1 || phase1 > cm.n_chunks / 3) return hipSuccess;
-  // device buffers: [cost n] [ctl LPT_CTL] [list LPT_CLASSES x n]; the descriptor itself travels as a kernel argument
-  const size_t words = (size_t)n_blocks * (1 + LPT_CLASSES) + LPT_CTL;
+  // layout: [descriptor, 64 B] [cost n] [ctl LPT_CTL] [list LPT_CLASSES x n]
+  const size_t words = 16 + (size_t)n_blocks * (1 + LPT_CLASSES) + LPT_CTL;
   hipError_t e = grow((void**)&s->d_lpt, &s->lpt_bytes, words * sizeof(uint32_t));
   if (e != hipSuccess) return e;
-  LptQueue& q = cm.lpt;
-  q.cost = s->d_lpt, q.ctl = q.cost + n_blocks, q.list = q.ctl + LPT_CTL;
+  LptQueue q;
+  memset(&q, 0, sizeof(q));
+  static_assert(sizeof(LptQueue) <= 64, "descriptor slot");
+  q.cost = s->d_lpt + 16, q.ctl = q.cost + n_blocks, q.list = q.ctl + LPT_CTL;
   q.n_blocks = n_blocks, q.phase1 = phase1;
   q.phase2_base = phase1 * cm.pix_work;
   q.span = LPT_BLOCK * (cm.n_chunks - phase1);
   q.mode = (uint32_t)s->lpt, q.shift = (uint32_t)s->lpt_shift;
+  // descriptor and zeroed counters travel on the launch stream: ordered with the render kernels before and after
+  hipLaunchKernelGGL(write_lpt_descriptor, dim3(1), dim3(1), 0, stream, reinterpret_cast<LptQueue*>(s->d_lpt), q);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
   s->lpt_desc = q;
   e = hipMemsetAsync(q.cost, 0, ((size_t)n_blocks + LPT_CTL) * sizeof(uint32_t), stream);
   if (e != hipSuccess) return e;
-  cm.lpt_on = 1;
+  cm.lpt = reinterpret_cast<const LptQueue*>(s->d_lpt);
   cm.lpt_samples = phase1 * cm.chunk;
   cm.lpt_deep = (uint32_t)s->lpt_deep;
   return hipSuccess;
@@ -727,6 +733,16 @@ int rtg_scene_create(rtg_builder* b, const rtg_id* world, size_t n, int device, 
   s->dev.perlin_perm = (const uint8_t*)s->buffers[5];
   s->dev.n_prog = s->n_prog;
   s->dev.n_mat = s->n_mat;
+  if ((fs.features & (FEAT_ALL | FEAT_BOUNDARY)) == 0) {  // lean program (BOX / SPHERE / END): layout of its LDS image (rt_pool.h)
+    std::vector<uint32_t> ops(fs.hi.size()), off(fs.hi.size());
+    for (size_t i = 0; i < fs.hi.size(); i++) ops[i] = fs.hi[i].w[3];
+    s->dev.lds_image_bytes = lds_image_offsets(ops.data(), ops.size(), off.data());
+    if ((rc = upload(&s->buffers[6], off.data(), off.size() * sizeof(uint32_t), &s->bytes))) {
+      rtg_scene_destroy(s);
+      return rc;
+    }
+    s->dev.lds_off = (const uint32_t*)s->buffers[6];
+  }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->num_cus = prop.multiProcessorCount;
   if (s->num_cus <= 0) s->num_cus = 256;
