@@ -38,6 +38,9 @@ enum Op : uint32_t {
   OP_MEDIUM = 6,  // lo = (density, -, -, -)             hi = (end_pc, -, material, op|flags); boundary = records (pc, end_pc)
   OP_PRISM = 7,   // lo = (p0.x, p1.x, p0.y, p1.y)       hi = (p0.z, p1.z, material, op|flags): rect_prism(p0, p1, material)
                   //      (object.rs:420-473), its six Rect::hit in the And-tree's order inside ONE instruction
+  OP_BEND = 8,    // hi = (-, -, medium_pc, op): end of the record stream of a MEDIUM whose boundary is an object graph
+                  //      (F_GENERAL_BOUNDARY).  The main walk never reaches it (MEDIUM.end_pc points behind it); a walk that
+                  //      runs the boundary's stream as a range query (rt_pool_full.h GENB) finishes the query here.
 };
 
 // flag bits in hi.w above the 8-bit opcode
@@ -63,7 +66,7 @@ enum XformKind : uint32_t {
   XF_FLIP = 4,       //                                  object.rs:241-253
 };
 
-constexpr int MAX_XFORM_DEPTH = 4;  // PUSH nesting the kernel's ray stack holds
+constexpr int MAX_XFORM_DEPTH = 4;  // PUSH nesting the kernel's ray stack holds (a medium's boundary stream starts a fresh count)
 
 // Material record, 32 bytes (two uint4): lo = (c.r, c.g, c.b, param) hi = (texture, -, -, kind|texkind<<8)
 //   Lambertian / Isotropic: c = albedo when the texture is constant, else `texture` indexes tex[]

@@ -53,7 +53,16 @@ __device__ __attribute__((noinline)) float event_draw_f32(uint64_t seed, uint32_
 #define RT_FULL_TEX_THREADS 1024  // the textured variant wants ~142 VGPRs; capped at 128 it spills ~25 of them to scratch but
                                   // runs 16 instead of 12 waves per CU: measured 4 % faster on book-2 (768 = no spills)
 #endif
-template <int PROG, bool TEX, bool COUNT>
+// GENB: the scene holds a ConstantMedium whose boundary is an object graph (F_GENERAL_BOUNDARY, e.g. the book's smoke
+// boxes: ConstantMedium<Translate<RotateY<And<...>>>>, object.rs:533-575).  Its two boundary queries
+// (`boundary.hit(f32::MIN..f32::MAX)`, then `boundary.hit(t1 + 0.0001..f32::MAX)`, object.rs:551-552) run THROUGH THE SAME
+// WALK: at such a MEDIUM record the lane enters the boundary's own record stream in "boundary mode" (bmode 1, then 2) --
+// the range (t_lo, best) becomes the query's, hits only shrink `best` (no hit record), the main walk's `best` waits in
+// b_saved -- and the stream's closing OP_BEND record finishes the query: restart for query 2, or compute the medium's hit
+// and resume the main walk behind the stream.  The boundary's BOX records run in the box loop and its primitives in the
+// slow passes like any others, so a complex boundary is scheduled as well as the rest of the scene.  A template variant:
+// 5 more VGPRs, paid only by scenes that need it.
+template <int PROG, bool TEX, bool COUNT, bool GENB = false>
 __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_pool(DevScene sc, DevCamera cam, DevParams P, float* __restrict__ out,
                                                         uint32_t total_work, uint32_t* __restrict__ queue,
                                                         unsigned long long* counters, PoolTuning tune, ChunkMode cm,
@@ -63,6 +72,8 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   // footprint) compiled in
   constexpr uint32_t FEAT = FEAT_XFORM | FEAT_MEDIUM | FEAT_RECT | (TEX ? FEAT_TEXTURE : 0u);
   extern __shared__ uint4 s_mem[];
+  constexpr uint32_t OP_SLOW_LAST = GENB ? (uint32_t)OP_BEND : (uint32_t)OP_PRISM;  // records a slow pass executes
+  constexpr uint32_t STACK_LEVELS = GENB ? 2 * MAX_XFORM_DEPTH : MAX_XFORM_DEPTH;   // a boundary stream nests below the medium's own wrappers
   constexpr bool USE_LDS = PROG != 0;
   const uint32_t staged = USE_LDS ? 2u * window : 0u;  // uint4 units; pc = 16 r, hi[] of the window at +16 window
   const uint32_t win_bytes = 16u * window;
@@ -83,7 +94,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   const size_t gwave = (size_t)blockIdx.x * n_waves + wave;
   uint32_t* slot = g_slots + gwave * (FPOOL * FPOOL_FIELDS);
   float* slotf = reinterpret_cast<float*>(slot);
-  float* stack = g_stack + gwave * (MAX_XFORM_DEPTH * 6 * 64);  // [level][component][lane]
+  float* stack = g_stack + gwave * (STACK_LEVELS * 6 * 64);  // [level][component][lane]
   uint16_t* tlist = reinterpret_cast<uint16_t*>(s_mem + staged) + wave * (3u * FPOOL);
   uint16_t* slist = tlist + FPOOL;  // finished rays whose material needs no texture lookup (and slots without a ray)
   uint16_t* xlist = slist + FPOOL;  // finished rays that hit a checker / Perlin textured material
@@ -113,51 +124,89 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   uint32_t hmat = NO_HIT;            // NO_HIT = None
   uint32_t depth = 0, tag = 0, nhits = 0, root_hits = 0, ev_draws = 0;
   uint32_t r_pixel = 0, r_sample = 0, r_event = 0;  // RNG stream of this ray's event (media)
+  uint32_t bmode = 0;                                // GENB: 0 = main walk, 1 / 2 = inside a boundary stream, query 1 / 2
+  float t_lo = t_near, b_saved = 0.f, b_t1 = 0.f;    // GENB: lower end of the current range; the main walk's best; query 1's t
   Counts cnt = {0, 0, 0, 0};
   uint32_t total_draws = 0;
   uint32_t n_box_it = 0, n_box_lanes = 0, n_slow_it = 0, n_slow_lanes = 0, n_shade = 0, n_shade_lanes = 0, n_refill = 0;
   unsigned long long t_shade = 0, t_serv = 0, t_box = 0, t_slow = 0, t_mark = 0, t_mark2 = 0;  // COUNT: s_memtime shares
+
+  // ConstantMedium::hit once both boundary queries hit at t1, t2 (object.rs:553-574): clamp to the range, one draw from the
+  // event's stream, exponential free path.  `med_lo / med_hi` = the MEDIUM record (density, material, flags).
+  auto medium_between = [&](float t1, float t2, const uint4 med_lo, const uint4 med_hi, const V3 o, const V3 d, float& best, V3& hp,
+                            V3& hn, uint32_t& hmat, const uint32_t depth, uint32_t& tag, uint32_t& nhits, const uint32_t root_hits,
+                            uint32_t& ev_draws, const uint32_t r_pixel, const uint32_t r_sample, const uint32_t r_event) {
+    t1 = rs_max(t1, t_near);
+    t2 = rs_min(t2, best);
+    if (!(t1 >= t2)) {
+      const float len = vlen(d);
+      float distance_inside = (t2 - t1) * len;
+      float hit_distance = -(1.f / u2f(med_lo.x)) * rt_logf(event_draw_f32(seed, r_pixel, r_sample, r_event, ev_draws));
+      ev_draws++;
+      if (COUNT) total_draws++;
+      if (hit_distance < distance_inside) {
+        float t = t1 + hit_distance / len;
+        bool accept = !(med_hi.w & F_UNDER_BVH) || nhits == root_hits || !(best < t);
+        if (accept) {
+          hp = vadd(o, smul(t, d)), hn = mk(1.f, 0.f, 0.f), hmat = med_hi.z | ((med_hi.w & F_TEXTURED) << 12);
+          best = t, tag = depth, nhits++;
+        }
+      }
+    }
+  };
 
   // One non-BOX record for one ray.  The ray's registers are passed explicitly: the traversal lanes run
   // it on their own ray, the list pass on rays it loads from path slots.
   auto exec_op = [&](const uint32_t op, V3& o, V3& d, V3& inv, const float time, float& best, uint32_t& pc, const uint4 cur_lo,
                      const uint4 cur_hi, V3& hp, V3& hn, uint32_t& hmat, uint32_t& depth, uint32_t& tag, uint32_t& nhits,
                      const uint32_t root_hits, uint32_t& ev_draws, const uint32_t r_pixel, const uint32_t r_sample,
-                     const uint32_t r_event, float* stack) {
+                     const uint32_t r_event, float* stack, uint32_t& bmode, float& t_lo, float& b_saved, float& b_t1) {
     if (op == OP_SPHERE) {  // Sphere::hit, object.rs:84-111 (+ fused Translate / FlipNormals)
       if (COUNT) cnt.prim++;
       const V3 off = mk(u2f(cur_lo.x), u2f(cur_lo.y), u2f(cur_lo.z));
       V3 lo_o = o;
       if (cur_hi.w & F_TRANSLATE) lo_o = vsub(o, off);
       float t;
-      if (sphere_hit_t(lo_o, d, u2f(cur_lo.w), t_near, best, t)) {
-        V3 p = vadd(lo_o, smul(t, d));
-        V3 n = sdiv(p, u2f(cur_lo.w));
-        if (cur_hi.w & F_TRANSLATE) p = vadd(p, off);
-        if (cur_hi.w & F_FLIP) n = vneg(n);
-        hp = p, hn = n, hmat = cur_hi.z | ((cur_hi.w & F_TEXTURED) << 12);
-        best = t, tag = depth, nhits++;
+      if (sphere_hit_t(lo_o, d, u2f(cur_lo.w), GENB ? t_lo : t_near, best, t)) {
+        if (GENB && bmode) {
+          best = t;  // boundary query: only the closest t matters
+        } else {
+          V3 p = vadd(lo_o, smul(t, d));
+          V3 n = sdiv(p, u2f(cur_lo.w));
+          if (cur_hi.w & F_TRANSLATE) p = vadd(p, off);
+          if (cur_hi.w & F_FLIP) n = vneg(n);
+          hp = p, hn = n, hmat = cur_hi.z | ((cur_hi.w & F_TEXTURED) << 12);
+          best = t, tag = depth, nhits++;
+        }
       }
       pc += 16u;
     } else if (op == OP_RECT) {  // Rect::hit, object.rs:185-218
       if (COUNT) cnt.prim++;
       const uint32_t axis = (cur_hi.w >> F_AXIS_SHIFT) & 3u;
       float t;
-      if (rect_hit_t(o, d, axis, u2f(cur_lo.x), u2f(cur_lo.y), u2f(cur_lo.z), u2f(cur_lo.w), u2f(cur_hi.x), t_near, best, t)) {
-        V3 n = mk(axis == 0 ? 1.f : 0.f, axis == 1 ? 1.f : 0.f, axis == 2 ? 1.f : 0.f);
-        if (cur_hi.w & F_FLIP) n = vneg(n);
-        hp = vadd(o, smul(t, d)), hn = n, hmat = cur_hi.z | ((cur_hi.w & F_TEXTURED) << 12);
-        best = t, tag = depth, nhits++;
+      if (rect_hit_t(o, d, axis, u2f(cur_lo.x), u2f(cur_lo.y), u2f(cur_lo.z), u2f(cur_lo.w), u2f(cur_hi.x), GENB ? t_lo : t_near, best, t)) {
+        if (GENB && bmode) {
+          best = t;
+        } else {
+          V3 n = mk(axis == 0 ? 1.f : 0.f, axis == 1 ? 1.f : 0.f, axis == 2 ? 1.f : 0.f);
+          if (cur_hi.w & F_FLIP) n = vneg(n);
+          hp = vadd(o, smul(t, d)), hn = n, hmat = cur_hi.z | ((cur_hi.w & F_TEXTURED) << 12);
+          best = t, tag = depth, nhits++;
+        }
       }
       pc += 16u;
     } else if (op == OP_PRISM) {  // rect_prism: six Rect::hit in one instruction
       if (COUNT) cnt.prim += 6;
       float t;
       uint32_t face = 0;
-      const uint32_t nh = prism_hit_t(cur_lo, cur_hi, o, d, t_near, best, t, face);
+      const uint32_t nh = prism_hit_t(cur_lo, cur_hi, o, d, GENB ? t_lo : t_near, best, t, face);
       if (nh) {
-        hp = vadd(o, smul(t, d)), hn = prism_normal(face), hmat = cur_hi.z | ((cur_hi.w & F_TEXTURED) << 12);
-        best = t, tag = depth, nhits += nh;
+        if (GENB && bmode) {
+          best = t;
+        } else {
+          hp = vadd(o, smul(t, d)), hn = prism_normal(face), hmat = cur_hi.z | ((cur_hi.w & F_TEXTURED) << 12);
+          best = t, tag = depth, nhits += nh;
+        }
       }
       pc += 16u;
     } else if (op == OP_PUSH) {
@@ -201,40 +250,43 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
       if (kind == XF_ROTATE_Y || kind == XF_SCALE) inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
       pc += 16u;
     } else if (op == OP_MEDIUM) {  // ConstantMedium::hit, object.rs:545-575
-      // (scenes whose medium boundary is an object graph -- F_GENERAL_BOUNDARY -- are routed to the
-      // baseline kernel by the host: the nested boundary walk would cost every scene ~20 VGPRs here)
-      const uint4 blo = RT_FETCH_LO(pc + 16u), bhi = RT_FETCH_HI(pc + 16u);
-      float t1, t2;
-      uint32_t n_tests;
-      const bool crossed = boundary_pair_t(blo, bhi, o, d, t1, t2, n_tests);
-      if (COUNT) cnt.prim += n_tests;
-      if (crossed) {
-        t1 = rs_max(t1, t_near);
-        t2 = rs_min(t2, best);
-        if (!(t1 >= t2)) {
-          const float len = vlen(d);
-          float distance_inside = (t2 - t1) * len;
-          float hit_distance = -(1.f / u2f(cur_lo.x)) * rt_logf(event_draw_f32(seed, r_pixel, r_sample, r_event, ev_draws));
-          ev_draws++;
-          if (COUNT) total_draws++;
-          if (hit_distance < distance_inside) {
-            float t = t1 + hit_distance / len;
-            bool accept = !(cur_hi.w & F_UNDER_BVH) || nhits == root_hits || !(best < t);
-            if (accept) {
-              hp = vadd(o, smul(t, d)), hn = mk(1.f, 0.f, 0.f), hmat = cur_hi.z | ((cur_hi.w & F_TEXTURED) << 12);
-              best = t, tag = depth, nhits++;
-            }
-          }
-        }
+      if (GENB && (cur_hi.w & F_GENERAL_BOUNDARY)) {
+        // enter the boundary's stream for query 1 (object.rs:551): range f32::MIN..f32::MAX; the stream's OP_BEND continues
+        bmode = 1u, b_saved = best, best = F32_MAX, t_lo = -F32_MAX;
+        pc += 16u;
+      } else {
+        const uint4 blo = RT_FETCH_LO(pc + 16u), bhi = RT_FETCH_HI(pc + 16u);
+        float t1, t2;
+        uint32_t n_tests;
+        const bool crossed = boundary_pair_t(blo, bhi, o, d, t1, t2, n_tests);
+        if (COUNT) cnt.prim += n_tests;
+        if (crossed) medium_between(t1, t2, cur_lo, cur_hi, o, d, best, hp, hn, hmat, depth, tag, nhits, root_hits, ev_draws, r_pixel, r_sample, r_event);
+        pc = cur_hi.x;  // first record after the boundary's stream
       }
-      pc = cur_hi.x;  // first record after the boundary's stream
+    } else if (GENB && op == OP_BEND) {  // end of a general boundary's stream: `best` < MAX <=> the query hit
+      const bool any = best < F32_MAX;
+      const uint32_t med_pc = cur_hi.z * 16u;
+      if (any && bmode == 1u) {  // query 2 (object.rs:552): range t1 + 0.0001..f32::MAX over the same stream
+        b_t1 = best;
+        t_lo = best + 0.0001f, best = F32_MAX, bmode = 2u;
+        pc = med_pc + 16u;
+      } else {
+        const float t2 = best;
+        best = b_saved, t_lo = t_near;
+        if (any) {  // both queries hit: object.rs:553-574 with the MEDIUM record's density / material
+          const uint4 mlo = RT_FETCH_LO(med_pc), mhi = RT_FETCH_HI(med_pc);
+          medium_between(b_t1, t2, mlo, mhi, o, d, best, hp, hn, hmat, depth, tag, nhits, root_hits, ev_draws, r_pixel, r_sample, r_event);
+        }
+        bmode = 0u;
+        pc += 16u;  // MEDIUM.end_pc = the record behind this one
+      }
     }
   };
 
   for (;;) {
     uint32_t op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
     const uint64_t m_box = __builtin_amdgcn_ballot_w64(op == OP_BOX);
-    const uint64_t m_slow = __builtin_amdgcn_ballot_w64(op >= OP_SPHERE && op <= OP_PRISM);
+    const uint64_t m_slow = __builtin_amdgcn_ballot_w64(op >= OP_SPHERE && op <= OP_SLOW_LAST);
     const uint32_t n_busy = (uint32_t)__builtin_popcountll(m_box | m_slow);
     // ============================== SERVICE ======================================================
     if (64u - n_busy >= tune.refill_min || n_busy == 0) {
@@ -461,6 +513,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
             inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
             pc = 0, best = F32_MAX, hmat = NO_HIT;
             depth = 0, tag = 0, nhits = 0, root_hits = 0, ev_draws = 0;
+            bmode = 0, t_lo = t_near;
             cur_lo = RT_FETCH_LO(0), cur_hi = RT_FETCH_HI(0);
             have_ray = true;
           }
@@ -480,7 +533,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
     // Lanes at a gather point (head of a list-level run of records every ray executes in the same order)
     // are held until `gather_min` of them wait there -- or nothing else can run -- and then walk the run
     // together: one record kind per iteration, many lanes wide, instead of a few lanes per kind.
-    const bool is_slow = op >= OP_SPHERE && op <= OP_PRISM;
+    const bool is_slow = op >= OP_SPHERE && op <= OP_SLOW_LAST;
     const bool at_gather = is_slow && (cur_hi.w & F_GATHER) != 0u;
     const uint64_t b_gather = __builtin_amdgcn_ballot_w64(at_gather);
     const bool release = (uint32_t)__builtin_popcountll(b_gather) >= tune.gather_min ||
@@ -496,7 +549,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         if (COUNT) n_box_it++;
         if (op == OP_BOX) {  // Aabb::hit, aabb.rs:16-27 (1/d and its sign re-read: d changes under RotateY/Scale)
           if (COUNT) cnt.aabb++;
-          if (hi_is_root(cur_hi)) root_hits = nhits;
+          if (hi_is_root(cur_hi)) root_hits = nhits;  // (never set inside a boundary stream: the flattener leaves those roots unmarked)
           // plain f32 math: packed v_pk_* instructions are slower than the pairs they replace on gfx950 (rt_pool.h RT_PK_MATH)
           f32x2 tx, ty, tz;
           tx.x = (u2f(cur_lo.x) - o.x) * inv.x, tx.y = (u2f(cur_lo.y) - o.x) * inv.x;
@@ -505,7 +558,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           float ax = inv.x < 0.f ? tx.y : tx.x, bx = inv.x < 0.f ? tx.x : tx.y;
           float ay = inv.y < 0.f ? ty.y : ty.x, by = inv.y < 0.f ? ty.x : ty.y;
           float az = inv.z < 0.f ? tz.y : tz.x, bz = inv.z < 0.f ? tz.x : tz.y;
-          float start = rs_max(t_near, rs_max(rs_max(ax, ay), az));
+          float start = rs_max(GENB ? t_lo : t_near, rs_max(rs_max(ax, ay), az));
           float end = rs_min(best, rs_min(rs_min(bx, by), bz));
           pc = (end > start) ? pc + 16u : cur_hi.z;
           cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc);
@@ -523,20 +576,20 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
       if (!runnable) op = 0xfeu;  // held at a gather point: sits this pass out
 #pragma unroll 1
       for (uint32_t ahead = 0;; ahead++) {
-      if (COUNT) n_slow_it++, n_slow_lanes += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op >= OP_SPHERE && op <= OP_PRISM));
+      if (COUNT) n_slow_it++, n_slow_lanes += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op >= OP_SPHERE && op <= OP_SLOW_LAST));
       exec_op(op, o, d, inv, time, best, pc, cur_lo, cur_hi, hp, hn, hmat, depth, tag, nhits, root_hits, ev_draws, r_pixel, r_sample,
-              r_event, stack);
-      if (op >= OP_SPHERE && op <= OP_PRISM) {
+              r_event, stack, bmode, t_lo, b_saved, b_t1);
+      if (op >= OP_SPHERE && op <= OP_SLOW_LAST) {
         cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc), op = cur_hi.w & 0xffu;
         if ((cur_hi.w & F_GATHER) && !release) op = 0xfeu;  // arrived at a gather point: wait for the next batch
       }
       if (ahead + 1u >= tune.run_ahead) break;
-      if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op >= OP_SPHERE && op <= OP_PRISM)) < tune.run_ahead_min) break;
+      if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op >= OP_SPHERE && op <= OP_SLOW_LAST)) < tune.run_ahead_min) break;
       }
       if (COUNT) t_slow += RT_TICK() - t_mark;
     }
     op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
-    const uint32_t busy = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op >= OP_BOX && op <= OP_PRISM));
+    const uint32_t busy = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op >= OP_BOX && op <= OP_SLOW_LAST));
     if (64u - busy >= tune.refill_min || busy == 0) break;
     }
   }

@@ -153,9 +153,15 @@ RT_DEV bool boundary_pair_t(uint4 lo, uint4 hi, V3 o, V3 d, float& t1, float& t2
 // a nested walk over the boundary's own records [first, end) that only keeps the closest t.  Same
 // predicates and visiting order as hit_top; no hit record, no media.  Rare path -> out of line, program
 // read from global memory, private ray stack.
-template <bool COUNT>
-__device__ __attribute__((noinline)) bool boundary_hit_t(const DevScene& sc, uint32_t first, uint32_t end_pc, V3 o, V3 d,
-                                                         float time, float t_lo, float t_hi, float& t_out, Counts& cnt) {
+// Everything travels by value (program pointers in, {hit, t, test counts} out): no caller object has its address taken.
+struct BoundaryHit {
+  float t;
+  uint32_t any, n_aabb, n_prim;
+};
+__device__ __attribute__((noinline)) BoundaryHit boundary_hit_t(const uint4* __restrict__ prog_lo, const uint4* __restrict__ prog_hi,
+                                                                uint32_t first, uint32_t end_pc, V3 o, V3 d, float time,
+                                                                float t_lo, float t_hi) {
+  uint32_t n_aabb = 0, n_prim = 0;
   V3 inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
   float best = t_hi;
   bool any = false;
@@ -163,10 +169,10 @@ __device__ __attribute__((noinline)) bool boundary_hit_t(const DevScene& sc, uin
   V3 so[MAX_XFORM_DEPTH], sd[MAX_XFORM_DEPTH];
   uint32_t pc = first;
   while (pc < end_pc) {
-    const uint4 hi = sc.hi[pc], lo = sc.lo[pc];
+    const uint4 hi = prog_hi[pc], lo = prog_lo[pc];
     const uint32_t op = hi.w & 0xffu;
     if (op == OP_BOX) {
-      if (COUNT) cnt.aabb++;
+      n_aabb++;
       float t0x = (u2f(lo.x) - o.x) * inv.x, t1x = (u2f(lo.y) - o.x) * inv.x;
       float t0y = (u2f(lo.z) - o.y) * inv.y, t1y = (u2f(lo.w) - o.y) * inv.y;
       float t0z = (u2f(hi.x) - o.z) * inv.z, t1z = (u2f(hi.y) - o.z) * inv.z;
@@ -177,20 +183,20 @@ __device__ __attribute__((noinline)) bool boundary_hit_t(const DevScene& sc, uin
       float fin = rs_min(best, rs_min(rs_min(bx, by), bz));
       pc = (fin > start) ? pc + 1 : hi.z;
     } else if (op == OP_SPHERE) {
-      if (COUNT) cnt.prim++;
+      n_prim++;
       V3 lo_o = o;
       if (hi.w & F_TRANSLATE) lo_o = vsub(o, mk(u2f(lo.x), u2f(lo.y), u2f(lo.z)));
       float t;
       if (sphere_hit_t(lo_o, d, u2f(lo.w), t_lo, best, t)) best = t, any = true;
       pc++;
     } else if (op == OP_RECT) {
-      if (COUNT) cnt.prim++;
+      n_prim++;
       float t;
       if (rect_hit_t(o, d, (hi.w >> F_AXIS_SHIFT) & 3u, u2f(lo.x), u2f(lo.y), u2f(lo.z), u2f(lo.w), u2f(hi.x), t_lo, best, t))
         best = t, any = true;
       pc++;
     } else if (op == OP_PRISM) {
-      if (COUNT) cnt.prim += 6;
+      n_prim += 6;
       float t;
       uint32_t face;
       if (prism_hit_t(lo, hi, o, d, t_lo, best, t, face)) best = t, any = true;
@@ -223,8 +229,7 @@ __device__ __attribute__((noinline)) bool boundary_hit_t(const DevScene& sc, uin
       pc++;
     }
   }
-  t_out = best;
-  return any;
+  return BoundaryHit{best, any ? 1u : 0u, n_aabb, n_prim};
 }
 
 // World::hit_top (lib.rs:33-55) over the flat program.  `best` plays `nearest` / the shrinking
@@ -349,14 +354,18 @@ RT_DEV bool hit_top(const DevScene& sc, V3 o, V3 d, float time, float t_near, Sa
       float t1, t2;
       bool h1, h2 = false;
       if (general) {
-        h1 = boundary_hit_t<COUNT>(sc, pc + 1, hi.x, o, d, time, -F32_MAX, F32_MAX, t1, cnt);
+        const BoundaryHit b1 = boundary_hit_t(sc.lo, sc.hi, pc + 1, hi.x, o, d, time, -F32_MAX, F32_MAX);
+        h1 = b1.any != 0u, t1 = b1.t;
+        if (COUNT) cnt.aabb += b1.n_aabb, cnt.prim += b1.n_prim;
       } else {
         if (COUNT) cnt.prim++;
         h1 = prim_hit_t(blo, bhi, o, d, -F32_MAX, F32_MAX, t1);
       }
       if (h1) {
         if (general) {
-          h2 = boundary_hit_t<COUNT>(sc, pc + 1, hi.x, o, d, time, t1 + 0.0001f, F32_MAX, t2, cnt);
+          const BoundaryHit b2 = boundary_hit_t(sc.lo, sc.hi, pc + 1, hi.x, o, d, time, t1 + 0.0001f, F32_MAX);
+          h2 = b2.any != 0u, t2 = b2.t;
+          if (COUNT) cnt.aabb += b2.n_aabb, cnt.prim += b2.n_prim;
         } else {
           if (COUNT) cnt.prim++;
           h2 = prim_hit_t(blo, bhi, o, d, t1 + 0.0001f, F32_MAX, t2);

@@ -369,7 +369,12 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
   const size_t lds = full_pool_lds_bytes(window, waves);
   void (*kernel)(DevScene, DevCamera, DevParams, float*, uint32_t, uint32_t*, unsigned long long*, PoolTuning, ChunkMode,
                  uint32_t*, float*, uint32_t);
-  if (prog == 0) kernel = tex ? render_full_pool<0, true, COUNT> : render_full_pool<0, false, COUNT>;
+  const bool genb = (s->features & FEAT_BOUNDARY) != 0;  // a medium bounded by an object graph: the nested-walk variant
+  if (genb) {
+    if (prog == 0) kernel = tex ? render_full_pool<0, true, COUNT, true> : render_full_pool<0, false, COUNT, true>;
+    else if (prog == 1) kernel = tex ? render_full_pool<1, true, COUNT, true> : render_full_pool<1, false, COUNT, true>;
+    else kernel = tex ? render_full_pool<2, true, COUNT, true> : render_full_pool<2, false, COUNT, true>;
+  } else if (prog == 0) kernel = tex ? render_full_pool<0, true, COUNT> : render_full_pool<0, false, COUNT>;
   else if (prog == 1) kernel = tex ? render_full_pool<1, true, COUNT> : render_full_pool<1, false, COUNT>;
   else kernel = tex ? render_full_pool<2, true, COUNT> : render_full_pool<2, false, COUNT>;
   e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -386,7 +391,7 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
   if (e != hipSuccess) return e;
   e = grow((void**)&s->d_slots, &s->slots_bytes, (size_t)grid * waves * FPOOL * FPOOL_FIELDS * sizeof(uint32_t));
   if (e != hipSuccess) return e;
-  e = grow((void**)&s->d_stack, &s->stack_bytes, (size_t)grid * waves * MAX_XFORM_DEPTH * 6 * 64 * sizeof(float));
+  e = grow((void**)&s->d_stack, &s->stack_bytes, (size_t)grid * waves * (genb ? 2 : 1) * MAX_XFORM_DEPTH * 6 * 64 * sizeof(float));
   if (e != hipSuccess) return e;
   if (s->verbose)
     fprintf(stderr, "[rtg] full pool: grid %u x %d threads, %d WG/CU, lds %zu B (program window: %u of %u records), cost-ordered queue after %u chunk(s)\n",
@@ -407,7 +412,7 @@ static hipError_t launch_render(rtg_scene* s, const DevCamera& cam, const DevPar
   const uint32_t geom = s->features & (FEAT_ALL | FEAT_BOUNDARY);
   const bool accum_zero = !(s->features & FEAT_WIDE_ALBEDO) && (!(s->features & FEAT_BRIGHT_ALBEDO) || d.max_bounces <= 63u);
   const bool pool_ok = accum_zero && s->kernel_version >= 3 && d.nx <= 0xffffu && d.ny <= 0xffffu;
-  if (geom != 0 && !(geom & FEAT_BOUNDARY) && pool_ok) {
+  if (geom != 0 && pool_ok) {
     hipError_t e = launch_full_pool<COUNT>(s, cam, d, d_out, stream);
     if (e != hipErrorNotSupported) return e;
   }

@@ -342,7 +342,7 @@ void SceneBuilder::emit(uint32_t id, bool under_bvh, bool and_in_bvh, int depth,
     case HostObject::BVH: {
       size_t root = out->lo.size();
       emit_bvh((int32_t)o.a, depth, out, in_boundary);
-      if (!under_bvh) out->hi[root].w[3] |= F_BVH_ROOT;
+      if (!under_bvh && !in_boundary) out->hi[root].w[3] |= F_BVH_ROOT;  // (a boundary query keeps no hit record: no merge rule)
       return;
     }
     case HostObject::MEDIUM: {
@@ -357,8 +357,12 @@ void SceneBuilder::emit(uint32_t id, bool under_bvh, bool and_in_bvh, int depth,
              OP_MEDIUM | (under_bvh ? F_UNDER_BVH : 0u) | (single ? 0u : F_GENERAL_BOUNDARY) | mat_flags(*this, o.mat));
         // the boundary's own stream: evaluated twice per medium test by a nested walk (object.rs:551-552),
         // skipped by the main walk.  It starts a fresh wrapper depth (its rays are saved on a private stack).
-        if (single) fuse_primitive(*this, o.a, out, true);
-        else emit(o.a, false, false, 0, out, true), out->features |= FEAT_BOUNDARY;
+        if (single) {
+          fuse_primitive(*this, o.a, out, true);
+        } else {
+          emit(o.a, false, false, 0, out, true), out->features |= FEAT_BOUNDARY;
+          push(out, 0, 0, 0, 0, 0, 0, (uint32_t)at, OP_BEND);  // where a range-query walk of the stream finishes
+        }
         out->hi[at].w[0] = (uint32_t)out->lo.size();  // end_pc
       }
       out->features |= FEAT_MEDIUM;

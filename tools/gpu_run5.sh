@@ -1,0 +1,9 @@
+O=gpurun_out/r02e; mkdir -p $O
+python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+tail -5 $O/pytest.log
+python tools/time_scenes.py cornell_smoke 300 300 100 cornell 300 300 100 book2 800 800 100 book2_bvh 800 800 100 volume 300 300 100 > $O/time_scenes.txt 2>&1
+RTG_VERBOSE=1 python tools/time_scenes.py book2 800 800 100 2>&1 | grep "^\[rtg\]" | sort -u > $O/schedule_book2.txt
+RTG_VERBOSE=1 python tools/time_scenes.py cornell 300 300 100 2>&1 | grep "^\[rtg\]" | sort -u > $O/schedule_cornell.txt
+for gm in 16 24 32 40 48; do RTG_GATHER_MIN=$gm python tools/time_scenes.py book2 800 800 100 2>&1 | grep "^book2" | sed "s/^/gather_min $gm /" >> $O/sweep_book2.txt; done
+for rm in 12 20 28; do RTG_REFILL_MIN=$rm python tools/time_scenes.py book2 800 800 100 2>&1 | grep "^book2" | sed "s/^/refill_min $rm /" >> $O/sweep_book2.txt; done
+cat $O/time_scenes.txt $O/schedule_book2.txt $O/schedule_cornell.txt $O/sweep_book2.txt
