@@ -70,6 +70,7 @@ typedef struct rtg_params {
 } rtg_params;
 
 #define RTG_FLAG_COUNTERS 1u /* fill rtg_stats counters (instrumented kernel variant, slower) */
+#define RTG_FLAG_TRACE_KERNEL 2u /* rtg_debug_samples: trace the production ray-pool kernel instead of the one-lane probe */
 
 typedef struct rtg_stats {
   uint32_t struct_size; /* = sizeof(rtg_stats)                                                */
@@ -188,7 +189,12 @@ int rtg_tonemap_device(int device, size_t n, const float* d_rgb, uint8_t* d_out_
 int rtg_debug_hit_top(rtg_scene* s, size_t n, const float* rays, uint64_t seed, float t_near,
                       float* out, uint32_t* out_material);
 /* One sample of par_cast's closure (lib.rs:366-372) per (x, y, sample) triple, y counted from the
- * bottom as in the reference. out_rgb: n x 3; out_info: n x 4 (bounces, draws, aabb_tests, prim_tests). */
+ * bottom as in the reference. out_rgb: n x 3; out_info: n x 4 (bounces, draws, aabb_tests, prim_tests).
+ * Default: a one-lane-per-key probe kernel built from the same device functions as the baseline kernel.  With
+ * params->flags & RTG_FLAG_TRACE_KERNEL the WHOLE frame (nx, ny, ns, rank / nranks of `params`) is rendered by the
+ * instrumented variant of the production kernel par_cast uses for this scene, with a per-sample trace table switched
+ * on, and the keys are read out of it -- so a broken schedule can be localised to a (pixel, sample).
+ * RTG_ERR_UNSUPPORTED when that kernel is the baseline one (nothing pooled to trace). */
 int rtg_debug_samples(rtg_scene* s, const rtg_camera* camera, const rtg_params* params, size_t n,
                       const uint32_t* xs, const uint32_t* ys, const uint32_t* samples,
                       float* out_rgb, uint32_t* out_info);

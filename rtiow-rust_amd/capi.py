@@ -16,6 +16,7 @@ c_u8p = C.POINTER(C.c_uint8)
 
 INVALID_ID = 0xFFFFFFFF
 FLAG_COUNTERS = 1
+FLAG_TRACE_KERNEL = 2
 
 
 class Camera(C.Structure):
@@ -385,8 +386,9 @@ class Scene:
                                              out.ctypes.data_as(c_f32p), mat.ctypes.data_as(c_u32p)))
         return out, mat
 
-    def debug_samples(self, camera, nx, ny, ns, xs, ys, samples, seed=0xDEADBEEF, **kw):
-        p = make_params(nx, ny, ns, seed=seed, **kw)
+    def debug_samples(self, camera, nx, ny, ns, xs, ys, samples, seed=0xDEADBEEF, trace_kernel=False, **kw):
+        """trace_kernel=True: read the keys out of the production ray-pool kernel's per-sample trace (whole frame rendered)."""
+        p = make_params(nx, ny, ns, seed=seed, flags=FLAG_TRACE_KERNEL if trace_kernel else 0, **kw)
         xs, ys, samples = (np.ascontiguousarray(a, dtype=np.uint32) for a in (xs, ys, samples))
         n = xs.size
         rgb = np.zeros((n, 3), dtype=np.float32)

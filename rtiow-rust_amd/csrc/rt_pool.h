@@ -418,6 +418,16 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
   uint32_t sgn_x = 0, sgn_y = 0, sgn_z = 0;  // staged: byte offset of this ray's plane pair inside each triple
   Counts cnt = {0, 0, 0, 0};
   uint32_t total_draws = 0;
+  // Per-sample trace (instrumented variant only, rtg_debug_samples on THIS kernel): counters[30] = base of the
+  // [sample][pixel work index] x {bounces, draws, Aabb tests, primitive tests} table, counters[31] = per-slot accumulators
+  // (draws | aabb | prim rows per wave); 0 = tracing off.  A ray's test counts are the lane's counters at finish minus refill.
+  uint32_t* tr_out = nullptr;
+  uint32_t* tr_slot = nullptr;
+  uint32_t tr_a0 = 0, tr_p0 = 0;
+  if (COUNT) {
+    tr_out = reinterpret_cast<uint32_t*>(counters[30]);
+    if (tr_out) tr_slot = reinterpret_cast<uint32_t*>(counters[31]) + ((size_t)blockIdx.x * n_waves + wave) * (POOL * 3u);
+  }
   uint32_t n_box_it = 0, n_box_lanes = 0, n_sph_it = 0, n_sph_lanes = 0, n_shade = 0, n_shade_lanes = 0, n_refill = 0;
   uint32_t n_end = 0, n_end_lanes = 0;
   unsigned long long t_shade = 0, t_serv = 0, t_box = 0, t_sph = 0, t_mark = 0, t_mark2 = 0;  // COUNT: s_memtime shares
@@ -475,6 +485,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
         if (fin) {
           BEST_F(my_slot) = best;
           put_bpc(my_slot, best_pc);
+          if (COUNT && tr_slot) tr_slot[POOL + my_slot] += cnt.aabb - tr_a0, tr_slot[2u * POOL + my_slot] += cnt.prim - tr_p0;
           if (to_e) elist[e_count + lane_rank(m_e)] = (uint16_t)my_slot;
           else slist[s_count + lane_rank(m_s)] = (uint16_t)my_slot;
           have_ray = false;
@@ -567,6 +578,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
             nd = rs;
           }
           if (COUNT) total_draws += rng.draws;
+          if (COUNT && tr_slot) tr_slot[j] += rng.draws;
           lpt_on = s < cm.lpt_samples && bounces == cm.lpt_deep;  // phase 1 of the cost-ordered queue: a deep scatter event
           if (lpt_on) lpt_blk = pixel_to_work(P, xy & 0xffffu, xy >> 16) >> 8;
           if (scattered) {
@@ -628,6 +640,10 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
             if (cm.scratch) {  // chunk mode: park the sample colour, folded in order afterwards
               float* sp = cm.scratch + 3ull * ((size_t)s * cm.pix_work + pixel_to_work(P, x, row));
               RT_SCRATCH_STORE(sp, result);
+              if (COUNT && tr_out) {
+                uint32_t* tp = tr_out + 4ull * ((size_t)s * cm.pix_work + pixel_to_work(P, x, row));
+                tp[0] = SLOT_U(PF_BOUNCES, j), tp[1] = tr_slot[j], tp[2] = tr_slot[POOL + j], tp[3] = tr_slot[2u * POOL + j];
+              }
             } else {
               col = vadd(mk(SLOT_F(PF_COL, j), SLOT_F(PF_COL + 1, j), SLOT_F(PF_COL + 2, j)), result);  // vec3.rs:195-203
             }
@@ -695,6 +711,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           float time;
           get_ray(cam, u, v, rng, so, sd, time);
           if (COUNT) total_draws += rng.draws, cnt.rays++;
+          if (COUNT && tr_slot) tr_slot[j] = rng.draws, tr_slot[POOL + j] = 0u, tr_slot[2u * POOL + j] = 0u;
           RAY_F(PF_O, j) = so.x, RAY_F(PF_O + 1, j) = so.y, RAY_F(PF_O + 2, j) = so.z;
           RAY_F(PF_D, j) = sd.x, RAY_F(PF_D + 1, j) = sd.y, RAY_F(PF_D + 2, j) = sd.z;
           if (!cm.scratch) SLOT_F(PF_COL, j) = col.x, SLOT_F(PF_COL + 1, j) = col.y, SLOT_F(PF_COL + 2, j) = col.z;
@@ -722,6 +739,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
             inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);  // aabb.rs:17
             sgn_x = inv.x < 0.f ? 32u : 8u, sgn_y = inv.y < 0.f ? 40u : 16u, sgn_z = inv.z < 0.f ? 48u : 24u;  // aabb.rs:20-23
             pc = pc0, best = F32_MAX, best_pc = NO_HIT, best_flags = 0;
+            if (COUNT) tr_a0 = cnt.aabb, tr_p0 = cnt.prim;
             RT_LOAD_REC();
             have_ray = true;
           }

@@ -128,6 +128,13 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   float t_lo = t_near, b_saved = 0.f, b_t1 = 0.f;    // GENB: lower end of the current range; the main walk's best; query 1's t
   Counts cnt = {0, 0, 0, 0};
   uint32_t total_draws = 0;
+  uint32_t* tr_out = nullptr;  // per-sample trace of the instrumented variant (rt_pool.h)
+  uint32_t* tr_slot = nullptr;
+  uint32_t tr_a0 = 0, tr_p0 = 0;
+  if (COUNT) {
+    tr_out = reinterpret_cast<uint32_t*>(counters[30]);
+    if (tr_out) tr_slot = reinterpret_cast<uint32_t*>(counters[31]) + gwave * (FPOOL * 3u);
+  }
   uint32_t n_box_it = 0, n_box_lanes = 0, n_slow_it = 0, n_slow_lanes = 0, n_shade = 0, n_shade_lanes = 0, n_refill = 0;
   unsigned long long t_shade = 0, t_serv = 0, t_box = 0, t_slow = 0, t_mark = 0, t_mark2 = 0;  // COUNT: s_memtime shares
 
@@ -303,6 +310,8 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           SLOT_F(FF_P, my_slot) = hp.x, SLOT_F(FF_P + 1, my_slot) = hp.y, SLOT_F(FF_P + 2, my_slot) = hp.z;
           SLOT_F(FF_N, my_slot) = hn.x, SLOT_F(FF_N + 1, my_slot) = hn.y, SLOT_F(FF_N + 2, my_slot) = hn.z;
           SLOT_U(FF_EVDRAWS, my_slot) = ev_draws;
+          if (COUNT && tr_slot)
+            tr_slot[my_slot] += ev_draws, tr_slot[FPOOL + my_slot] += cnt.aabb - tr_a0, tr_slot[2u * FPOOL + my_slot] += cnt.prim - tr_p0;
           if (to_x) xlist[x_count + lane_rank(m_x)] = (uint16_t)my_slot;
           else slist[s_count + lane_rank(m_fin)] = (uint16_t)my_slot;
           have_ray = false;
@@ -419,9 +428,14 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
               }
             }
             if (COUNT) total_draws += rng.draws;
+            if (COUNT && tr_slot) tr_slot[j] += rng.draws;
             if (ended) {
               float* sp = cm.scratch + 3ull * ((size_t)s * cm.pix_work + pixel_to_work(P, x, row));
               RT_SCRATCH_STORE(sp, result);
+              if (COUNT && tr_out) {
+                uint32_t* tp = tr_out + 4ull * ((size_t)s * cm.pix_work + pixel_to_work(P, x, row));
+                tp[0] = bounces, tp[1] = tr_slot[j], tp[2] = tr_slot[FPOOL + j], tp[3] = tr_slot[2u * FPOOL + j];
+              }
               s++;
               st = (s == P.ns || s % cm.chunk == 0u) ? ST_NEED_PIXEL : ST_GEN;
             } else {
@@ -472,6 +486,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           get_ray(cam, u, v, rng, so, sd, stime);
           accum = mk(0.f, 0.f, 0.f), strength = splat(1.f), bounces = 0;
           if (COUNT) total_draws += rng.draws;
+          if (COUNT && tr_slot) tr_slot[j] = rng.draws, tr_slot[FPOOL + j] = 0u, tr_slot[2u * FPOOL + j] = 0u;
           st = ST_TRAV;
         }
         const bool live = st == ST_TRAV;
@@ -514,6 +529,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
             pc = 0, best = F32_MAX, hmat = NO_HIT;
             depth = 0, tag = 0, nhits = 0, root_hits = 0, ev_draws = 0;
             bmode = 0, t_lo = t_near;
+            if (COUNT) tr_a0 = cnt.aabb, tr_p0 = cnt.prim;
             cur_lo = RT_FETCH_LO(0), cur_hi = RT_FETCH_HI(0);
             have_ray = true;
           }

@@ -173,6 +173,8 @@ struct rtg_scene {
   uint32_t* d_lpt = nullptr;   // cost-ordered work queue (rt_pool.h LptQueue)
   size_t lpt_bytes = 0;
   LptQueue lpt_desc{};         // descriptor of the last launch (RTG_VERBOSE histogram)
+  int last_kernel = 0;         // what launch_render chose last: 1 = baseline, 3 = lean ray pools, 4 = full-feature ray pools
+  uint32_t last_pix_work = 0;  // pixel work items of that launch (tiles x tile area), 0 when it kept no per-sample scratch
   int verbose = 0;
   int window = -1;             // full-feature kernel: records of the program staged in LDS (-1 = as many as fit)
   int ray_lds = 1;             // 0: all slot fields in global memory
@@ -234,6 +236,7 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
       cm.scratch = s->d_scratch;
     }
   }
+  s->last_pix_work = cm.scratch ? (uint32_t)pix_work : 0u;
   uint64_t total_work = pix_work * cm.n_chunks;
   if (total_work > 0xfffffffeull) return hipErrorInvalidValue;
   uint32_t* queue = (uint32_t*)(s->d_counters + 7);
@@ -352,6 +355,7 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
   if (e != hipSuccess) return e;
   ChunkMode cm{};
   cm.scratch = s->d_scratch, cm.chunk = 1u, cm.n_chunks = d.ns, cm.pix_work = (uint32_t)pix_work;
+  s->last_pix_work = (uint32_t)pix_work;
   uint32_t* queue = (uint32_t*)(s->d_counters + 7);
   e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
@@ -412,11 +416,18 @@ static hipError_t launch_render(rtg_scene* s, const DevCamera& cam, const DevPar
   const uint32_t geom = s->features & (FEAT_ALL | FEAT_BOUNDARY);
   const bool accum_zero = !(s->features & FEAT_WIDE_ALBEDO) && (!(s->features & FEAT_BRIGHT_ALBEDO) || d.max_bounces <= 63u);
   const bool pool_ok = accum_zero && s->kernel_version >= 3 && d.nx <= 0xffffu && d.ny <= 0xffffu;
+  s->last_kernel = 1;
   if (geom != 0 && pool_ok) {
     hipError_t e = launch_full_pool<COUNT>(s, cam, d, d_out, stream);
-    if (e != hipErrorNotSupported) return e;
+    if (e != hipErrorNotSupported) {
+      s->last_kernel = 4;
+      return e;
+    }
   }
-  if (geom == 0 && pool_ok) return launch_pool<COUNT>(s, cam, d, d_out, stream);
+  if (geom == 0 && pool_ok) {
+    s->last_kernel = 3;
+    return launch_pool<COUNT>(s, cam, d, d_out, stream);
+  }
   uint32_t nbx = (d.nx + 15) / 16, nby = (d.ny + 15) / 16;
   dim3 grid(nbx * nby), block(256);
   if (geom == 0)
@@ -1113,6 +1124,46 @@ int rtg_debug_samples(rtg_scene* s, const rtg_camera* camera, const rtg_params* 
   if (rc) return rc;
   if (!xs || !ys || !samples || !out_rgb || !out_info) return fail(RTG_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(s->device));
+  if (params->flags & RTG_FLAG_TRACE_KERNEL) {
+    // Trace the PRODUCTION kernel: render the whole frame with the instrumented variant of whatever kernel par_cast
+    // uses for this scene, with its per-sample trace table switched on, then pick the requested keys out of the table
+    // (colour: the per-sample scratch the ordered fold reads).
+    const uint32_t tiles_x = (d.nx + d.tile_w - 1) / d.tile_w, tiles_y = (d.ny + d.tile_h - 1) / d.tile_h;
+    const uint32_t tiles = tiles_x * tiles_y;
+    const uint64_t owned = tiles > d.rank ? (tiles - d.rank + d.nranks - 1) / d.nranks : 0;
+    const uint64_t pix_work = owned * d.tile_w * d.tile_h;
+    const size_t table = (size_t)4 * d.ns * pix_work, slots = (size_t)s->num_cus * 16 * std::max(FPOOL, POOL) * 3;
+    DevBuf<uint32_t> d_trace;
+    HIP_TRY(d_trace.alloc(table + slots));
+    HIP_TRY(hipMemset(d_trace.p, 0, (table + slots) * sizeof(uint32_t)));
+    HIP_TRY(grow((void**)&s->d_frame, &s->frame_bytes, (size_t)d.nx * d.ny * 3 * sizeof(float)));
+    HIP_TRY(hipMemset(s->d_counters, 0, 32 * sizeof(unsigned long long)));
+    const unsigned long long ptrs[2] = {(unsigned long long)(uintptr_t)d_trace.p, (unsigned long long)(uintptr_t)(d_trace.p + table)};
+    HIP_TRY(hipMemcpy(s->d_counters + 30, ptrs, sizeof(ptrs), hipMemcpyHostToDevice));
+    const DevCamera cam = to_dev(camera);
+    hipError_t e = launch_render<true>(s, cam, d, s->d_frame, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipMemset(s->d_counters + 30, 0, 2 * sizeof(unsigned long long));
+    if (e != hipSuccess) return hip_fail(e, "trace launch");
+    if (s->last_kernel < 3 || s->last_pix_work == 0)
+      return fail(RTG_ERR_UNSUPPORTED, "this scene / frame runs on the baseline kernel (or without the per-sample scratch): nothing to trace");
+    std::vector<uint32_t> h_trace(table);
+    std::vector<float> h_col((size_t)3 * d.ns * pix_work);
+    HIP_TRY(hipMemcpy(h_trace.data(), d_trace.p, table * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h_col.data(), s->d_scratch, h_col.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) {
+      const uint32_t x = xs[i], row = d.ny - 1u - ys[i], sm = samples[i];
+      const uint32_t tx = x / d.tile_w, ty = row / d.tile_h, tile = ty * tiles_x + tx;
+      if (x >= d.nx || ys[i] >= d.ny || sm >= d.ns || tile % d.nranks != d.rank) return fail(RTG_ERR_INVALID, "trace key outside this rank's frame");
+      const uint32_t k = tile / d.nranks, lx = x - tx * d.tile_w, ly = row - ty * d.tile_h;  // = pixel_to_work (rt_pool.h)
+      const uint32_t b = (ly >> 3) * (d.tile_w >> 3) + (lx >> 3);
+      const size_t w = (size_t)k * d.tile_w * d.tile_h + b * 64u + (ly & 7u) * 8u + (lx & 7u);
+      const size_t at = (size_t)sm * pix_work + w;
+      for (int c = 0; c < 3; c++) out_rgb[3 * i + c] = h_col[3 * at + c];
+      for (int c = 0; c < 4; c++) out_info[4 * i + c] = h_trace[4 * at + c];
+    }
+    return RTG_OK;
+  }
   DevBuf<uint32_t> dx, dy, ds, dinfo;
   DevBuf<float> drgb;
   HIP_TRY(dx.alloc(n));

@@ -70,6 +70,9 @@ CASES = {
     "volume_bvh": (_volume_in_bvh, 32, 32, 8),
     "simple_light": (lambda pkg, b, nx, ny: pkg.scenes.simple_light_scene(
         b, nx, ny, pkg.small_rng.SmallRng(0xDEADBEEF), spheres=200), 24, 24, 4),
+    # simple_light_scene at the reference's own size: 1000 spheres in a LIST world (main.rs:137, USE_BVH = false)
+    "simple_light_1000": (lambda pkg, b, nx, ny: pkg.scenes.simple_light_scene(
+        b, nx, ny, pkg.small_rng.SmallRng(0xDEADBEEF), spheres=1000), 24, 24, 4),
     "checker_scale": (_checker_scale, 32, 32, 8),
     "big_lean": (_big_lean, 40, 24, 6),
     "cornell_smoke": (_cornell_smoke, 32, 32, 8),

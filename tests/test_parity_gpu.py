@@ -50,6 +50,25 @@ def test_per_sample_traces(pkg, gpu, name):
     assert_bit_equal(rgb, g[name + ".rgb"], name)
 
 
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_per_sample_traces_of_the_production_kernels(pkg, gpu, name):
+    """The same 64 keys, read out of the per-sample trace table of the ray-pool kernel par_cast really runs for the scene
+    (instrumented variant of render_lean_pool / render_full_pool, RTG_FLAG_TRACE_KERNEL): colour, bounce count, RNG draws,
+    Aabb tests and primitive tests of every traced (pixel, sample) equal the oracle's -- a break in the schedule is
+    localised to a path, not just to a frame."""
+    g = np.load(os.path.join(GOLD, "samples.npz"))
+    xs, ys, ss = g[name + ".keys"]
+    sg, cam, nx, ny, ns = build_case(pkg, gpu, name)
+    rgb, info = sg.debug_samples(cam, nx, ny, ns, xs, ys, ss, trace_kernel=True)
+    assert np.array_equal(info, g[name + ".info"]), name
+    assert_bit_equal(rgb, g[name + ".rgb"], name)
+    # and on a shard: the table is indexed by the rank's own pixel work items
+    keep = [i for i in range(len(xs)) if (((ny - 1 - int(ys[i])) // 16) * ((nx + 15) // 16) + int(xs[i]) // 16) % 2 == 1]
+    if keep:
+        rgb2, info2 = sg.debug_samples(cam, nx, ny, ns, xs[keep], ys[keep], ss[keep], trace_kernel=True, rank=1, nranks=2)
+        assert np.array_equal(info2, g[name + ".info"][keep]) and np.array_equal(rgb2.view(np.uint32), g[name + ".rgb"][keep].view(np.uint32))
+
+
 @pytest.mark.parametrize("name", ["cornell", "book1", "book2", "volume_bvh", "checker_scale", "motion"])
 def test_hit_top_probes(pkg, gpu, oracle, name):
     """World::hit_top on random + edge-case rays (zero direction components, NaN t, in-plane rays)."""
