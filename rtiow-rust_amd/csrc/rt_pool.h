@@ -203,6 +203,30 @@ RT_DEV uint32_t pixel_to_work(const DevParams& P, uint32_t x, uint32_t row) {
   return k * (P.tile_w * P.tile_h) + b * 64u + (ly & 7u) * 8u + (lx & 7u);
 }
 
+// Launch constants live in device memory, not in the kernel arguments: camera, frame parameters and the chunk / queue
+// description are only read inside the SCATTER and END passes, and by-value copies would sit in (spilled) SGPRs across the
+// traversal loops -- SGPR spill code is VALU code (v_readlane / v_writelane), and 19 more spilled SGPRs once cost 8 % of a
+// C2 launch.  load_const reads through a laundered constant-address-space pointer: the loads stay scalar (s_load) and INSIDE
+// the pass (the compiler can neither hoist them out of the main loop nor treat them as loop-invariant).
+struct LaunchConsts {
+  DevCamera cam;
+  DevParams P;
+  ChunkMode cm;
+};
+typedef const __attribute__((address_space(4))) uint32_t* const_u32_ptr;
+template <typename T>
+RT_DEV T load_const(const T* p) {
+  static_assert(sizeof(T) % 4 == 0, "dword-sized");
+  const_u32_ptr w = (const_u32_ptr)(uintptr_t)p;
+  asm volatile("" : "+s"(w));
+  T c;
+  uint32_t* dst = reinterpret_cast<uint32_t*>(&c);
+#pragma unroll
+  for (uint32_t i = 0; i < sizeof(T) / 4u; i++) dst[i] = w[i];
+  return c;
+}
+__global__ void write_launch_consts(LaunchConsts* dst, LaunchConsts v) { *dst = v; }
+
 // stream-ordered update of the descriptor (a kernel argument by value: no host buffer has to outlive the call)
 __global__ void write_lpt_descriptor(LptQueue* dst, LptQueue v) { *dst = v; }
 
@@ -318,8 +342,8 @@ RT_DEV uint4 fetch_hi_global(const DevScene& sc, uint32_t idx) {  // byte-offset
 // program leaves room; the cold fields stay in the global SoA region.
 template <bool USE_LDS, bool COUNT, bool HOT_LDS>
 __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void render_lean_pool(
-    DevScene sc, DevCamera cam, DevParams P, float* __restrict__ out, uint32_t total_work, uint32_t* __restrict__ queue,
-    unsigned long long* counters, PoolTuning tune, ChunkMode cm, uint32_t* __restrict__ g_slots) {
+    DevScene sc, const LaunchConsts* __restrict__ lc, float* __restrict__ out, uint32_t total_work, uint32_t* __restrict__ queue,
+    unsigned long long* counters, PoolTuning tune, uint32_t* __restrict__ g_slots) {
   extern __shared__ uint4 s_mem[];
   const uint32_t n_prog = sc.n_prog;
   // Program counters are BYTE offsets: REC r.  Staged: into the LDS image above (a step needs no shift,
@@ -396,8 +420,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
   }
   __syncthreads();  // program staged, pools initialised (the only workgroup barrier)
 
-  const uint64_t seed = ((uint64_t)P.seed_hi << 32) | P.seed_lo;
-  const float t_near = P.t_near;
+  const float t_near = load_const(&lc->P.t_near);
   uint32_t t_count = 0, s_count = 0, e_count = POOL, n_dead = 0;  // wave-uniform list sizes / retired slots
   uint32_t w_next = 0, w_end = 0;                                  // this wave's reserved range of work items
   uint32_t w_chunk = 0, w_delta = 0;                               // ... their chunk, and pixel work index - item index
@@ -501,6 +524,9 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
         const uint32_t take = s_count < 64u ? s_count : 64u;
         s_count -= take;
         if (COUNT) n_shade++, n_shade_lanes += take, t_mark2 = RT_TICK();
+        const DevParams P = load_const(&lc->P);
+        const ChunkMode cm = load_const(&lc->cm);
+        const uint64_t seed = ((uint64_t)P.seed_hi << 32) | P.seed_lo;
         bool live = false, ended = false, lpt_on = false;
         uint32_t j = 0, lpt_blk = 0;
         if (lane < take) {
@@ -613,6 +639,9 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
         const uint32_t take = e_count < 64u ? e_count : 64u;
         e_count -= take;
         if (COUNT) n_end++, n_end_lanes += take, t_mark2 = RT_TICK();
+        const DevParams P = load_const(&lc->P);
+        const ChunkMode cm = load_const(&lc->cm);
+        const uint64_t seed = ((uint64_t)P.seed_hi << 32) | P.seed_lo;
         uint32_t st = ST_DEAD, j = 0, s = 0, x = 0, row = 0;
         V3 col = mk(0.f, 0.f, 0.f);
         if (lane < take) {
@@ -709,6 +738,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           float v = ((float)y + rng.gen_f32()) / (float)P.ny;
           V3 so, sd;
           float time;
+          const DevCamera cam = load_const(&lc->cam);
           get_ray(cam, u, v, rng, so, sd, time);
           if (COUNT) total_draws += rng.draws, cnt.rays++;
           if (COUNT && tr_slot) tr_slot[j] = rng.draws, tr_slot[POOL + j] = 0u, tr_slot[2u * POOL + j] = 0u;

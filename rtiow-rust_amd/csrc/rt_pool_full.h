@@ -63,9 +63,9 @@ __device__ __attribute__((noinline)) float event_draw_f32(uint64_t seed, uint32_
 // slow passes like any others, so a complex boundary is scheduled as well as the rest of the scene.  A template variant:
 // 5 more VGPRs, paid only by scenes that need it.
 template <int PROG, bool TEX, bool COUNT, bool GENB = false>
-__global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_pool(DevScene sc, DevCamera cam, DevParams P, float* __restrict__ out,
+__global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_pool(DevScene sc, const LaunchConsts* __restrict__ lc, float* __restrict__ out,
                                                         uint32_t total_work, uint32_t* __restrict__ queue,
-                                                        unsigned long long* counters, PoolTuning tune, ChunkMode cm,
+                                                        unsigned long long* counters, PoolTuning tune,
                                                         uint32_t* __restrict__ g_slots, float* __restrict__ g_stack,
                                                         uint32_t window) {
   // TEX = the scene references a checker / Perlin texture: only then is texture_eval (and its register
@@ -106,8 +106,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   }
   __syncthreads();
 
-  const uint64_t seed = ((uint64_t)P.seed_hi << 32) | P.seed_lo;
-  const float t_near = P.t_near;
+  const float t_near = load_const(&lc->P.t_near);
   uint32_t t_count = 0, s_count = FPOOL, x_count = 0, n_dead = 0;
   uint32_t w_next = 0, w_end = 0, w_chunk = 0, w_delta = 0;
   bool w_lpt_ready = false;
@@ -146,6 +145,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
     t1 = rs_max(t1, t_near);
     t2 = rs_min(t2, best);
     if (!(t1 >= t2)) {
+      const uint64_t seed = ((uint64_t)load_const(&lc->P.seed_hi) << 32) | load_const(&lc->P.seed_lo);
       const float len = vlen(d);
       float distance_inside = (t2 - t1) * len;
       float hit_distance = -(1.f / u2f(med_lo.x)) * rt_logf(event_draw_f32(seed, r_pixel, r_sample, r_event, ev_draws));
@@ -324,6 +324,9 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
       auto shade_pass = [&](auto textured_tag, uint16_t* list, uint32_t& count) {
         constexpr bool TEXTURED = decltype(textured_tag)::value;
         constexpr uint32_t PASS_FEAT = TEXTURED ? FEAT : (FEAT & ~FEAT_TEXTURE);
+        const DevParams P = load_const(&lc->P);
+        const ChunkMode cm = load_const(&lc->cm);
+        const uint64_t seed = ((uint64_t)P.seed_hi << 32) | P.seed_lo;
         const uint32_t take = count < 64u ? count : 64u;
         count -= take;
         if (COUNT) n_shade++, n_shade_lanes += take, t_mark2 = RT_TICK();
@@ -483,6 +486,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           rng.init(seed, y * P.nx + x, s);
           float u = ((float)x + rng.gen_f32()) / (float)P.nx;
           float v = ((float)y + rng.gen_f32()) / (float)P.ny;
+          const DevCamera cam = load_const(&lc->cam);
           get_ray(cam, u, v, rng, so, sd, stime);
           accum = mk(0.f, 0.f, 0.f), strength = splat(1.f), bounces = 0;
           if (COUNT) total_draws += rng.draws;
@@ -522,7 +526,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
             d = mk(SLOT_F(FF_D, my_slot), SLOT_F(FF_D + 1, my_slot), SLOT_F(FF_D + 2, my_slot));
             time = SLOT_F(FF_TIME, my_slot);
             const uint32_t xy = SLOT_U(FF_XY, my_slot);
-            r_pixel = (P.ny - 1u - (xy >> 16)) * P.nx + (xy & 0xffffu);
+            r_pixel = (load_const(&lc->P.ny) - 1u - (xy >> 16)) * load_const(&lc->P.nx) + (xy & 0xffffu);
             r_sample = SLOT_U(FF_SAMPLE, my_slot);
             r_event = SLOT_U(FF_BOUNCES, my_slot) + 1u;
             inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);

@@ -170,6 +170,7 @@ struct rtg_scene {
   float* d_scratch = nullptr;  // chunk-mode per-sample colours
   size_t scratch_bytes = 0;
   int force_chunks = 0;        // RTG_CHUNKS: 0 = automatic
+  LaunchConsts* d_consts = nullptr;  // camera / frame parameters / chunk description of the launch (rt_pool.h), written on the launch stream
   uint32_t* d_lpt = nullptr;   // cost-ordered work queue (rt_pool.h LptQueue)
   size_t lpt_bytes = 0;
   LptQueue lpt_desc{};         // descriptor of the last launch (RTG_VERBOSE histogram)
@@ -247,8 +248,7 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
   bool use_lds = image != 0 && pool_lds_bytes(image, s->n_mat, waves, true, false) <= lds_limit;
   bool ray_lds = s->ray_lds && pool_lds_bytes(image, s->n_mat, waves, use_lds, true) <= lds_limit;
   size_t lds = pool_lds_bytes(image, s->n_mat, waves, use_lds, ray_lds);
-  void (*kernel)(DevScene, DevCamera, DevParams, float*, uint32_t, uint32_t*, unsigned long long*, PoolTuning, ChunkMode,
-                 uint32_t*);
+  void (*kernel)(DevScene, const LaunchConsts*, float*, uint32_t, uint32_t*, unsigned long long*, PoolTuning, uint32_t*);
   if (ray_lds) kernel = use_lds ? render_lean_pool<true, COUNT, true> : render_lean_pool<false, COUNT, true>;
   else kernel = use_lds ? render_lean_pool<true, COUNT, false> : render_lean_pool<false, COUNT, false>;
   e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -277,8 +277,9 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
       s->slots_bytes = need;
     }
   }
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(bt), lds, stream, s->dev, cam, d, d_out, (uint32_t)total_work, queue,
-                     s->d_counters, s->pool_tune, cm, s->d_slots);
+  hipLaunchKernelGGL(write_launch_consts, dim3(1), dim3(1), 0, stream, s->d_consts, LaunchConsts{cam, d, cm});
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(bt), lds, stream, s->dev, (const LaunchConsts*)s->d_consts, d_out, (uint32_t)total_work, queue,
+                     s->d_counters, s->pool_tune, s->d_slots);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (cm.scratch) {
@@ -371,8 +372,8 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
     prog = window == 0 ? 0 : (window == s->n_prog ? 1 : 2);
   }
   const size_t lds = full_pool_lds_bytes(window, waves);
-  void (*kernel)(DevScene, DevCamera, DevParams, float*, uint32_t, uint32_t*, unsigned long long*, PoolTuning, ChunkMode,
-                 uint32_t*, float*, uint32_t);
+  void (*kernel)(DevScene, const LaunchConsts*, float*, uint32_t, uint32_t*, unsigned long long*, PoolTuning, uint32_t*, float*,
+                 uint32_t);
   const bool genb = (s->features & FEAT_BOUNDARY) != 0;  // a medium bounded by an object graph: the nested-walk variant
   if (genb) {
     if (prog == 0) kernel = tex ? render_full_pool<0, true, COUNT, true> : render_full_pool<0, false, COUNT, true>;
@@ -400,8 +401,9 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
   if (s->verbose)
     fprintf(stderr, "[rtg] full pool: grid %u x %d threads, %d WG/CU, lds %zu B (program window: %u of %u records), cost-ordered queue after %u chunk(s)\n",
             grid, bt, per_cu, lds, window, s->n_prog, cm.lpt_samples);
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(bt), lds, stream, s->dev, cam, d, d_out, (uint32_t)total_work, queue,
-                     s->d_counters, s->full_tune, cm, s->d_slots, s->d_stack, window);
+  hipLaunchKernelGGL(write_launch_consts, dim3(1), dim3(1), 0, stream, s->d_consts, LaunchConsts{cam, d, cm});
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(bt), lds, stream, s->dev, (const LaunchConsts*)s->d_consts, d_out, (uint32_t)total_work, queue,
+                     s->d_counters, s->full_tune, s->d_slots, s->d_stack, window);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(fold_samples_kernel, dim3((uint32_t)((pix_work + 255) / 256)), dim3(256), 0, stream, d, cm, d_out);
@@ -705,6 +707,7 @@ void rtg_scene_destroy(rtg_scene* s) {
   if (s->d_slots) (void)hipFree(s->d_slots);
   if (s->d_stack) (void)hipFree(s->d_stack);
   if (s->d_lpt) (void)hipFree(s->d_lpt);
+  if (s->d_consts) (void)hipFree(s->d_consts);
   if (s->d_frame) (void)hipFree(s->d_frame);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -762,7 +765,7 @@ int rtg_scene_create(rtg_builder* b, const rtg_id* world, size_t n, int device, 
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->num_cus = prop.multiProcessorCount;
   if (s->num_cus <= 0) s->num_cus = 256;
-  if (hipMalloc((void**)&s->d_counters, 32 * sizeof(unsigned long long)) != hipSuccess ||
+  if (hipMalloc((void**)&s->d_counters, 32 * sizeof(unsigned long long)) != hipSuccess || hipMalloc((void**)&s->d_consts, sizeof(LaunchConsts)) != hipSuccess ||
       hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
     rtg_scene_destroy(s);
     return fail(RTG_ERR_DEVICE, "scene: counter/event allocation failed");
