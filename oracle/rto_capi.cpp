@@ -543,30 +543,45 @@ int rto_debug_glibc(int op, size_t n, const float* in, float* out) {
   return 0;
 }
 
-// Exhaustive distance scan: compares rt_* with glibc over [lo_bits, hi_bits] (float bit patterns,
-// step `stride`), returns #mismatches and max ulp distance.
+// Distance scan: compares the restatements (rto_libm.hpp) with the PLATFORM libm over [lo_bits, hi_bits] (float bit
+// patterns, step `stride`) on all hardware threads; returns #mismatches and the max ulp distance (NaN == NaN).
 int rto_debug_ulp_scan(int op, uint32_t lo_bits, uint32_t hi_bits, uint32_t stride,
                        uint64_t* n_tested, uint64_t* n_mismatch, uint32_t* max_ulp) {
-  uint64_t tested = 0, mism = 0;
-  uint32_t worst = 0;
-  for (uint64_t b = lo_bits; b <= hi_bits; b += stride) {
-    float x = f32_from_bits((uint32_t)b);
-    float a, g;
-    if (op == 0) a = rt_logf(x), g = logf(x);
-    else if (op == 1) a = rt_pow5f(x), g = powf(x, 5.f);
-    else a = rt_sinf(x), g = sinf(x);
-    tested++;
-    uint32_t ua = f32_bits(a), ug = f32_bits(g);
-    if (ua != ug) {
-      if ((a != a) && (g != g)) continue;
-      mism++;
-      int64_t ia = (ua & 0x80000000u) ? -(int64_t)(ua & 0x7fffffffu) : (int64_t)ua;
-      int64_t ig = (ug & 0x80000000u) ? -(int64_t)(ug & 0x7fffffffu) : (int64_t)ug;
-      uint64_t d = (uint64_t)(ia > ig ? ia - ig : ig - ia);
-      if (d > worst) worst = (uint32_t)(d > 0xffffffffu ? 0xffffffffu : d);
+  int nt = (int)std::thread::hardware_concurrency();
+  if (nt < 1) nt = 1;
+  if (nt > 64) nt = 64;
+  std::vector<uint64_t> tested(nt, 0), mism(nt, 0);
+  std::vector<uint32_t> worst(nt, 0);
+  const uint64_t total = ((uint64_t)hi_bits - lo_bits) / stride + 1;
+  auto work = [&](int t) {
+    const uint64_t i0 = total * t / nt, i1 = total * (t + 1) / nt;
+    uint64_t my_tested = 0, my_mism = 0;  // (locals: the per-thread slots share cache lines)
+    uint32_t my_worst = 0;
+    for (uint64_t i = i0; i < i1; i++) {
+      float x = f32_from_bits((uint32_t)(lo_bits + i * stride));
+      float a, g;
+      if (op == 0) a = rt_logf(x), g = logf(x);
+      else if (op == 1) a = rt_pow5f(x), g = powf(x, 5.f);
+      else a = rt_sinf(x), g = sinf(x);
+      my_tested++;
+      uint32_t ua = f32_bits(a), ug = f32_bits(g);
+      if (ua != ug) {
+        if ((a != a) && (g != g)) continue;
+        my_mism++;
+        int64_t ia = (ua & 0x80000000u) ? -(int64_t)(ua & 0x7fffffffu) : (int64_t)ua;
+        int64_t ig = (ug & 0x80000000u) ? -(int64_t)(ug & 0x7fffffffu) : (int64_t)ug;
+        uint64_t d = (uint64_t)(ia > ig ? ia - ig : ig - ia);
+        if (d > my_worst) my_worst = (uint32_t)(d > 0xffffffffu ? 0xffffffffu : d);
+      }
     }
-  }
-  *n_tested = tested, *n_mismatch = mism, *max_ulp = worst;
+    tested[t] = my_tested, mism[t] = my_mism, worst[t] = my_worst;
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nt; t++) pool.emplace_back(work, t);
+  work(0);
+  for (auto& t : pool) t.join();
+  *n_tested = 0, *n_mismatch = 0, *max_ulp = 0;
+  for (int t = 0; t < nt; t++) *n_tested += tested[t], *n_mismatch += mism[t], *max_ulp = std::max(*max_ulp, worst[t]);
   return 0;
 }
 

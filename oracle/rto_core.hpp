@@ -13,6 +13,8 @@
 #include <cstring>
 #include <limits>
 
+#include "rto_libm.hpp"
+
 namespace rto {
 
 // ------------------------------------------------------------------------------------------------
@@ -134,19 +136,6 @@ struct Aabb {
   }
 };
 
-// ------------------------------------------------------------------------------------------------
-// Shared libm restatements.  The reference calls f32::ln (object.rs:562), f32::powf(x, 5.)
-// (material.rs:145) and f32::sin (texture.rs:14) which lower to the platform libm; the GPU cannot
-// call glibc, so BOTH sides run the same f64-internal algorithms (these, and the copies in
-// rtiow-rust_amd/csrc/rt_libm.h).  tests/ report their distance to this host's glibc.
-// ------------------------------------------------------------------------------------------------
-struct LogfEntry {
-  double invc, logc;
-};
-static const LogfEntry kLogfTable[128] = {
-#include "rto_logf_table.inc"
-};
-
 inline uint32_t f32_bits(float f) {
   uint32_t u;
   std::memcpy(&u, &f, 4);
@@ -156,76 +145,6 @@ inline float f32_from_bits(uint32_t u) {
   float f;
   std::memcpy(&f, &u, 4);
   return f;
-}
-
-inline float rt_logf(float x) {
-  uint32_t ix = f32_bits(x);
-  if (ix == 0u || ix == 0x80000000u) return -std::numeric_limits<float>::infinity();  // ln(0) = -inf
-  if (ix >= 0x7f800000u) {                                     // negative, inf, nan
-    if (ix == 0x7f800000u) return x;                           // ln(+inf) = +inf
-    return std::numeric_limits<float>::quiet_NaN();
-  }
-  int sub = 0;
-  if (ix < 0x00800000u) {  // subnormal: scale by 2^23 (exact)
-    ix = f32_bits(x * 8388608.0f);
-    sub = 23;
-  }
-  uint32_t tmp = ix - 0x3f328000u;
-  int k = (int)((int32_t)tmp >> 23) - sub;
-  uint32_t i = (tmp >> 16) & 127u;
-  uint32_t iz = ix - (tmp & 0xff800000u);
-  double z = (double)f32_from_bits(iz);
-  double r = z * kLogfTable[i].invc - 1.0;
-  double y0 = (double)k * 0x1.62e42fefa39efp-1 + kLogfTable[i].logc;
-  // log1p(r) = r - r^2/2 + r^3/3 - r^4/4 + r^5/5 - r^6/6, |r| <= 2^-8 (truncation <= 2^-58)
-  double p = -1.0 / 6.0;
-  p = p * r + 0.2;
-  p = p * r + -0.25;
-  p = p * r + (1.0 / 3.0);
-  p = p * r + -0.5;
-  double r2 = r * r;
-  double y = y0 + (r + r2 * p);
-  return (float)y;
-}
-
-// powf(x, 5.) for the Schlick term (material.rs:145): exact products in f64, one rounding to f32.
-inline float rt_pow5f(float x) {
-  double d = (double)x;
-  double d2 = d * d;
-  double d4 = d2 * d2;
-  return (float)(d4 * d);
-}
-
-// f32::sin for the checker texture (texture.rs:14): f64 Cody-Waite reduction + Taylor kernels.
-// Accurate (<1 ulp f32) for |x| < ~1e6; larger arguments lose accuracy gracefully (documented).
-inline float rt_sinf(float x) {
-  if (!(std::fabs(x) <= 3.0e38f)) return std::numeric_limits<float>::quiet_NaN();  // inf / nan
-  double y = (double)x;
-  double n = __builtin_rint(y * 0x1.45f306dc9c883p-1);  // y * 2/pi, round to nearest even
-  // pi/2 = HI + LO, HI has 33 significant bits so n*HI is exact for |n| < 2^20
-  double r = (y - n * 0x1.921fb544p+0) - n * 0x1.0b4611a626331p-34;
-  double r2 = r * r;
-  int q = (int)((long long)n & 3);
-  // Taylor kernels on |r| <= pi/4 (truncation < 1e-16); coefficients are exact 1/n! quotients
-  // that both compilers fold to the same correctly rounded double.
-  double ps = -1.0 / 1307674368000.0;      // -1/15!
-  ps = ps * r2 + 1.0 / 6227020800.0;       // +1/13!
-  ps = ps * r2 + -1.0 / 39916800.0;        // -1/11!
-  ps = ps * r2 + 1.0 / 362880.0;           // +1/9!
-  ps = ps * r2 + -1.0 / 5040.0;            // -1/7!
-  ps = ps * r2 + 1.0 / 120.0;              // +1/5!
-  ps = ps * r2 + -1.0 / 6.0;               // -1/3!
-  double s = r + r * (r2 * ps);
-  double pc = 1.0 / 20922789888000.0;      // +1/16!
-  pc = pc * r2 + -1.0 / 87178291200.0;     // -1/14!
-  pc = pc * r2 + 1.0 / 479001600.0;        // +1/12!
-  pc = pc * r2 + -1.0 / 3628800.0;         // -1/10!
-  pc = pc * r2 + 1.0 / 40320.0;            // +1/8!
-  pc = pc * r2 + -1.0 / 720.0;             // -1/6!
-  pc = pc * r2 + 1.0 / 24.0;               // +1/4!
-  double c = (1.0 - 0.5 * r2) + (r2 * r2) * pc;
-  double v = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
-  return (float)v;
 }
 
 // ------------------------------------------------------------------------------------------------

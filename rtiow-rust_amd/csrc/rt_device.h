@@ -1,13 +1,15 @@
 // rt_device.h -- scalar building blocks of the hot path as gfx950 device code:
 //   V3 arithmetic in the reference's exact operation order (src/vec3.rs),
 //   the per-(pixel,sample) counter RNG (Philox4x32-10) with rand-0.6.5's float conversions,
-//   and the libm restatements (ln / powf(.,5) / sin) that must agree bit-for-bit with the CPU side.
+//   (the libm restatements -- ln / powf(., 5) / sin, pinned to glibc -- live in rt_libm.h).
 //
 // Compile with -ffp-contract=off: rustc never fuses a*b+c, hipcc would (v_fmac_f32).  f32 divide and
 // sqrt stay correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt is the hipcc default).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include "rt_libm.h"
 
 #define RT_DEV __device__ __forceinline__
 
@@ -39,81 +41,6 @@ RT_DEV float rs_min(float a, float b) { return __builtin_fminf(a, b); }
 RT_DEV V3 reflect(V3 v, V3 n) { return vsub(v, smul(2.f * vdot(v, n), n)); }
 
 constexpr float F32_MAX = 3.402823466e+38f;
-
-// ---- libm restatements (the CPU checker runs the same algorithms; parity tests compare them) ------
-struct LogfEntry {
-  double invc, logc;
-};
-__device__ const LogfEntry kLogfTable[128] = {
-#include "rt_logf_table.inc"
-};
-
-// f32::ln (object.rs:562): table (128 intervals, OFF = 0x3f328000 puts 1.0 mid-interval with c = 1)
-// + degree-6 log1p polynomial, all in f64, one final rounding to f32.
-__device__ __attribute__((noinline)) float rt_logf(float x) {  // rare (one call per medium evaluation): out of line
-  uint32_t ix = __float_as_uint(x);
-  if (ix == 0u || ix == 0x80000000u) return -__builtin_inff();
-  if (ix >= 0x7f800000u) {
-    if (ix == 0x7f800000u) return x;
-    return __builtin_nanf("");
-  }
-  int sub = 0;
-  if (ix < 0x00800000u) {
-    ix = __float_as_uint(x * 8388608.0f);
-    sub = 23;
-  }
-  uint32_t tmp = ix - 0x3f328000u;
-  int k = ((int32_t)tmp >> 23) - sub;
-  uint32_t i = (tmp >> 16) & 127u;
-  uint32_t iz = ix - (tmp & 0xff800000u);
-  double z = (double)__uint_as_float(iz);
-  double r = z * kLogfTable[i].invc - 1.0;
-  double y0 = (double)k * 0x1.62e42fefa39efp-1 + kLogfTable[i].logc;
-  double p = -1.0 / 6.0;
-  p = p * r + 0.2;
-  p = p * r + -0.25;
-  p = p * r + (1.0 / 3.0);
-  p = p * r + -0.5;
-  double r2 = r * r;
-  double y = y0 + (r + r2 * p);
-  return (float)y;
-}
-
-// f32::powf(x, 5.) of schlick (material.rs:145): exact-ish f64 products, one rounding.
-RT_DEV float rt_pow5f(float x) {
-  double d = (double)x;
-  double d2 = d * d;
-  double d4 = d2 * d2;
-  return (float)(d4 * d);
-}
-
-// f32::sin of the checker texture (texture.rs:14): f64 Cody-Waite + Taylor kernels.
-__device__ __attribute__((noinline)) float rt_sinf(float x) {  // rare (checker texture): kept out of line
-  if (!(__builtin_fabsf(x) <= 3.0e38f)) return __builtin_nanf("");
-  double y = (double)x;
-  double n = __builtin_rint(y * 0x1.45f306dc9c883p-1);
-  double r = (y - n * 0x1.921fb544p+0) - n * 0x1.0b4611a626331p-34;
-  double r2 = r * r;
-  int q = (int)((long long)n & 3);
-  double ps = -1.0 / 1307674368000.0;
-  ps = ps * r2 + 1.0 / 6227020800.0;
-  ps = ps * r2 + -1.0 / 39916800.0;
-  ps = ps * r2 + 1.0 / 362880.0;
-  ps = ps * r2 + -1.0 / 5040.0;
-  ps = ps * r2 + 1.0 / 120.0;
-  ps = ps * r2 + -1.0 / 6.0;
-  double s = r + r * (r2 * ps);
-  double pc = 1.0 / 20922789888000.0;
-  pc = pc * r2 + -1.0 / 87178291200.0;
-  pc = pc * r2 + 1.0 / 479001600.0;
-  pc = pc * r2 + -1.0 / 3628800.0;
-  pc = pc * r2 + 1.0 / 40320.0;
-  pc = pc * r2 + -1.0 / 720.0;
-  pc = pc * r2 + 1.0 / 24.0;
-  double c = (1.0 - 0.5 * r2) + (r2 * r2) * pc;
-  double v = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
-  return (float)v;
-}
 
 // ---- counter RNG ---------------------------------------------------------------------------------
 // Determinism contract: one Philox4x32-10 stream per (seed, pixel, sample, event); key =
