@@ -137,158 +137,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   uint32_t n_box_it = 0, n_box_lanes = 0, n_slow_it = 0, n_slow_lanes = 0, n_shade = 0, n_shade_lanes = 0, n_refill = 0;
   unsigned long long t_shade = 0, t_serv = 0, t_box = 0, t_slow = 0, t_mark = 0, t_mark2 = 0;  // COUNT: s_memtime shares
 
-  // ConstantMedium::hit once both boundary queries hit at t1, t2 (object.rs:553-574): clamp to the range, one draw from the
-  // event's stream, exponential free path.  `med_lo / med_hi` = the MEDIUM record (density, material, flags).
-  auto medium_between = [&](float t1, float t2, const uint4 med_lo, const uint4 med_hi, const V3 o, const V3 d, float& best, V3& hp,
-                            V3& hn, uint32_t& hmat, const uint32_t depth, uint32_t& tag, uint32_t& nhits, const uint32_t root_hits,
-                            uint32_t& ev_draws, const uint32_t r_pixel, const uint32_t r_sample, const uint32_t r_event) {
-    t1 = rs_max(t1, t_near);
-    t2 = rs_min(t2, best);
-    if (!(t1 >= t2)) {
-      const uint64_t seed = ((uint64_t)load_const(&lc->P.seed_hi) << 32) | load_const(&lc->P.seed_lo);
-      const float len = vlen(d);
-      float distance_inside = (t2 - t1) * len;
-      float hit_distance = -(1.f / u2f(med_lo.x)) * rt_logf(event_draw_f32(seed, r_pixel, r_sample, r_event, ev_draws));
-      ev_draws++;
-      if (COUNT) total_draws++;
-      if (hit_distance < distance_inside) {
-        float t = t1 + hit_distance / len;
-        bool accept = !(med_hi.w & F_UNDER_BVH) || nhits == root_hits || !(best < t);
-        if (accept) {
-          hp = vadd(o, smul(t, d)), hn = mk(1.f, 0.f, 0.f), hmat = med_hi.z | ((med_hi.w & F_TEXTURED) << 12);
-          best = t, tag = depth, nhits++;
-        }
-      }
-    }
-  };
-
-  // One non-BOX record for one ray.  The ray's registers are passed explicitly: the traversal lanes run
-  // it on their own ray, the list pass on rays it loads from path slots.
-  auto exec_op = [&](const uint32_t op, V3& o, V3& d, V3& inv, const float time, float& best, uint32_t& pc, const uint4 cur_lo,
-                     const uint4 cur_hi, V3& hp, V3& hn, uint32_t& hmat, uint32_t& depth, uint32_t& tag, uint32_t& nhits,
-                     const uint32_t root_hits, uint32_t& ev_draws, const uint32_t r_pixel, const uint32_t r_sample,
-                     const uint32_t r_event, float* stack, uint32_t& bmode, float& t_lo, float& b_saved, float& b_t1) {
-    if (op == OP_SPHERE) {  // Sphere::hit, object.rs:84-111 (+ fused Translate / FlipNormals)
-      if (COUNT) cnt.prim++;
-      const V3 off = mk(u2f(cur_lo.x), u2f(cur_lo.y), u2f(cur_lo.z));
-      V3 lo_o = o;
-      if (cur_hi.w & F_TRANSLATE) lo_o = vsub(o, off);
-      float t;
-      if (sphere_hit_t(lo_o, d, u2f(cur_lo.w), GENB ? t_lo : t_near, best, t)) {
-        if (GENB && bmode) {
-          best = t;  // boundary query: only the closest t matters
-        } else {
-          V3 p = vadd(lo_o, smul(t, d));
-          V3 n = sdiv(p, u2f(cur_lo.w));
-          if (cur_hi.w & F_TRANSLATE) p = vadd(p, off);
-          if (cur_hi.w & F_FLIP) n = vneg(n);
-          hp = p, hn = n, hmat = cur_hi.z | ((cur_hi.w & F_TEXTURED) << 12);
-          best = t, tag = depth, nhits++;
-        }
-      }
-      pc += 16u;
-    } else if (op == OP_RECT) {  // Rect::hit, object.rs:185-218
-      if (COUNT) cnt.prim++;
-      const uint32_t axis = (cur_hi.w >> F_AXIS_SHIFT) & 3u;
-      float t;
-      if (rect_hit_t(o, d, axis, u2f(cur_lo.x), u2f(cur_lo.y), u2f(cur_lo.z), u2f(cur_lo.w), u2f(cur_hi.x), GENB ? t_lo : t_near, best, t)) {
-        if (GENB && bmode) {
-          best = t;
-        } else {
-          V3 n = mk(axis == 0 ? 1.f : 0.f, axis == 1 ? 1.f : 0.f, axis == 2 ? 1.f : 0.f);
-          if (cur_hi.w & F_FLIP) n = vneg(n);
-          hp = vadd(o, smul(t, d)), hn = n, hmat = cur_hi.z | ((cur_hi.w & F_TEXTURED) << 12);
-          best = t, tag = depth, nhits++;
-        }
-      }
-      pc += 16u;
-    } else if (op == OP_PRISM) {  // rect_prism: six Rect::hit in one instruction
-      if (COUNT) cnt.prim += 6;
-      float t;
-      uint32_t face = 0;
-      const uint32_t nh = prism_hit_t(cur_lo, cur_hi, o, d, GENB ? t_lo : t_near, best, t, face);
-      if (nh) {
-        if (GENB && bmode) {
-          best = t;
-        } else {
-          hp = vadd(o, smul(t, d)), hn = prism_normal(face), hmat = cur_hi.z | ((cur_hi.w & F_TEXTURED) << 12);
-          best = t, tag = depth, nhits += nh;
-        }
-      }
-      pc += 16u;
-    } else if (op == OP_PUSH) {
-      const uint32_t kind = (cur_hi.w >> F_KIND_SHIFT) & 7u;
-      float* sp = stack + depth * (6u * 64u) + lane;
-      sp[0] = o.x, sp[64] = o.y, sp[128] = o.z, sp[192] = d.x, sp[256] = d.y, sp[320] = d.z;
-      depth++;
-      const V3 a = mk(u2f(cur_lo.x), u2f(cur_lo.y), u2f(cur_lo.z));
-      if (cur_hi.w & F_PRE_TRANSLATE) o = vsub(o, mk(u2f(cur_lo.w), u2f(cur_hi.x), u2f(cur_hi.y)));
-      if (kind == XF_TRANSLATE) {
-        o = vsub(o, a);
-      } else if (kind == XF_ROTATE_Y) {
-        o = rot_y(o, -a.x, a.y), d = rot_y(d, -a.x, a.y);
-        inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
-      } else if (kind == XF_SCALE) {
-        o = vdiv(o, a), d = vdiv(d, a);
-        inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
-      } else if (kind == XF_MOVE) {
-        o = vsub(o, smul(time, a));
-      }
-      pc += 16u;
-    } else if (op == OP_POP) {
-      const uint32_t kind = (cur_hi.w >> F_KIND_SHIFT) & 7u;
-      depth--;
-      if (hmat != NO_HIT && tag == depth + 1u) {
-        const V3 a = mk(u2f(cur_lo.x), u2f(cur_lo.y), u2f(cur_lo.z));
-        if (kind == XF_TRANSLATE) {
-          hp = vadd(hp, a);
-        } else if (kind == XF_ROTATE_Y) {
-          hp = rot_y(hp, a.x, a.y), hn = rot_y(hn, a.x, a.y);
-        } else if (kind == XF_SCALE) {
-          hp = vmul(hp, a), hn = vdiv(hn, a);
-        } else if (kind == XF_FLIP) {
-          hn = vneg(hn);
-        }
-        if (cur_hi.w & F_PRE_TRANSLATE) hp = vadd(hp, mk(u2f(cur_lo.w), u2f(cur_hi.x), u2f(cur_hi.y)));
-        tag = depth;
-      }
-      const float* sp = stack + depth * (6u * 64u) + lane;
-      o = mk(sp[0], sp[64], sp[128]), d = mk(sp[192], sp[256], sp[320]);
-      if (kind == XF_ROTATE_Y || kind == XF_SCALE) inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
-      pc += 16u;
-    } else if (op == OP_MEDIUM) {  // ConstantMedium::hit, object.rs:545-575
-      if (GENB && (cur_hi.w & F_GENERAL_BOUNDARY)) {
-        // enter the boundary's stream for query 1 (object.rs:551): range f32::MIN..f32::MAX; the stream's OP_BEND continues
-        bmode = 1u, b_saved = best, best = F32_MAX, t_lo = -F32_MAX;
-        pc += 16u;
-      } else {
-        const uint4 blo = RT_FETCH_LO(pc + 16u), bhi = RT_FETCH_HI(pc + 16u);
-        float t1, t2;
-        uint32_t n_tests;
-        const bool crossed = boundary_pair_t(blo, bhi, o, d, t1, t2, n_tests);
-        if (COUNT) cnt.prim += n_tests;
-        if (crossed) medium_between(t1, t2, cur_lo, cur_hi, o, d, best, hp, hn, hmat, depth, tag, nhits, root_hits, ev_draws, r_pixel, r_sample, r_event);
-        pc = cur_hi.x;  // first record after the boundary's stream
-      }
-    } else if (GENB && op == OP_BEND) {  // end of a general boundary's stream: `best` < MAX <=> the query hit
-      const bool any = best < F32_MAX;
-      const uint32_t med_pc = cur_hi.z * 16u;
-      if (any && bmode == 1u) {  // query 2 (object.rs:552): range t1 + 0.0001..f32::MAX over the same stream
-        b_t1 = best;
-        t_lo = best + 0.0001f, best = F32_MAX, bmode = 2u;
-        pc = med_pc + 16u;
-      } else {
-        const float t2 = best;
-        best = b_saved, t_lo = t_near;
-        if (any) {  // both queries hit: object.rs:553-574 with the MEDIUM record's density / material
-          const uint4 mlo = RT_FETCH_LO(med_pc), mhi = RT_FETCH_HI(med_pc);
-          medium_between(b_t1, t2, mlo, mhi, o, d, best, hp, hn, hmat, depth, tag, nhits, root_hits, ev_draws, r_pixel, r_sample, r_event);
-        }
-        bmode = 0u;
-        pc += 16u;  // MEDIUM.end_pc = the record behind this one
-      }
-    }
-  };
+#include "rt_full_ops.inc"
 
   for (;;) {
     uint32_t op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
@@ -549,65 +398,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
     // ============================== TRAVERSE ======================================================
     // box runs and slow passes alternate in this inner loop until a service is due (rt_pool.h)
     for (;;) {
-    const uint64_t b_box = __builtin_amdgcn_ballot_w64(op == OP_BOX);
-    // Lanes at a gather point (head of a list-level run of records every ray executes in the same order)
-    // are held until `gather_min` of them wait there -- or nothing else can run -- and then walk the run
-    // together: one record kind per iteration, many lanes wide, instead of a few lanes per kind.
-    const bool is_slow = op >= OP_SPHERE && op <= OP_SLOW_LAST;
-    const bool at_gather = is_slow && (cur_hi.w & F_GATHER) != 0u;
-    const uint64_t b_gather = __builtin_amdgcn_ballot_w64(at_gather);
-    const bool release = (uint32_t)__builtin_popcountll(b_gather) >= tune.gather_min ||
-                         (b_box == 0 && __builtin_amdgcn_ballot_w64(is_slow && !at_gather) == 0);
-    const bool runnable = is_slow && (!at_gather || release);
-    const uint64_t b_slow = __builtin_amdgcn_ballot_w64(runnable);
-    if (b_box != 0 && (uint32_t)__builtin_popcountll(b_slow) < tune.sphere_min) {
-      const uint32_t n0 = (uint32_t)__builtin_popcountll(b_box);
-      const uint32_t floor_lanes = n0 > tune.box_leave ? n0 - tune.box_leave : 0u;
-      uint32_t n_now;
-      if (COUNT) t_mark = RT_TICK();
-      do {
-        if (COUNT) n_box_it++;
-        if (op == OP_BOX) {  // Aabb::hit, aabb.rs:16-27 (1/d and its sign re-read: d changes under RotateY/Scale)
-          if (COUNT) cnt.aabb++;
-          if (hi_is_root(cur_hi)) root_hits = nhits;  // (never set inside a boundary stream: the flattener leaves those roots unmarked)
-          // plain f32 math: packed v_pk_* instructions are slower than the pairs they replace on gfx950 (rt_pool.h RT_PK_MATH)
-          f32x2 tx, ty, tz;
-          tx.x = (u2f(cur_lo.x) - o.x) * inv.x, tx.y = (u2f(cur_lo.y) - o.x) * inv.x;
-          ty.x = (u2f(cur_lo.z) - o.y) * inv.y, ty.y = (u2f(cur_lo.w) - o.y) * inv.y;
-          tz.x = (u2f(cur_hi.x) - o.z) * inv.z, tz.y = (u2f(cur_hi.y) - o.z) * inv.z;
-          float ax = inv.x < 0.f ? tx.y : tx.x, bx = inv.x < 0.f ? tx.x : tx.y;
-          float ay = inv.y < 0.f ? ty.y : ty.x, by = inv.y < 0.f ? ty.x : ty.y;
-          float az = inv.z < 0.f ? tz.y : tz.x, bz = inv.z < 0.f ? tz.x : tz.y;
-          float start = rs_max(GENB ? t_lo : t_near, rs_max(rs_max(ax, ay), az));
-          float end = rs_min(best, rs_min(rs_min(bx, by), bz));
-          pc = (end > start) ? pc + 16u : cur_hi.z;
-          cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc);
-          op = cur_hi.w & 0xffu;
-        }
-        n_now = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op == OP_BOX));
-        if (COUNT) n_box_lanes += n_now;
-      } while (n_now > floor_lanes);
-      if (COUNT) t_box += RT_TICK() - t_mark;
-    } else if (b_slow != 0) {
-      // ---- slow pass: every parked lane executes one record, then runs ahead through up to
-      // `run_ahead` - 1 more while enough lanes still sit on slow records (the objects of a list world
-      // are visited in the same order by every ray, so these lanes mostly share their next kinds) ----
-      if (COUNT) t_mark = RT_TICK();
-      if (!runnable) op = 0xfeu;  // held at a gather point: sits this pass out
-#pragma unroll 1
-      for (uint32_t ahead = 0;; ahead++) {
-      if (COUNT) n_slow_it++, n_slow_lanes += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op >= OP_SPHERE && op <= OP_SLOW_LAST));
-      exec_op(op, o, d, inv, time, best, pc, cur_lo, cur_hi, hp, hn, hmat, depth, tag, nhits, root_hits, ev_draws, r_pixel, r_sample,
-              r_event, stack, bmode, t_lo, b_saved, b_t1);
-      if (op >= OP_SPHERE && op <= OP_SLOW_LAST) {
-        cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc), op = cur_hi.w & 0xffu;
-        if ((cur_hi.w & F_GATHER) && !release) op = 0xfeu;  // arrived at a gather point: wait for the next batch
-      }
-      if (ahead + 1u >= tune.run_ahead) break;
-      if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op >= OP_SPHERE && op <= OP_SLOW_LAST)) < tune.run_ahead_min) break;
-      }
-      if (COUNT) t_slow += RT_TICK() - t_mark;
-    }
+#include "rt_full_traverse.inc"
     op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
     const uint32_t busy = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op >= OP_BOX && op <= OP_SLOW_LAST));
     if (64u - busy >= tune.refill_min || busy == 0) break;

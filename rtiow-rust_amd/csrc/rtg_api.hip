@@ -19,6 +19,7 @@
 #include "../../include/rtiow_gpu.h"
 #include "rt_pool.h"
 #include "rt_pool_full.h"
+#include "rt_sync_full.h"
 #include "rt_trace.h"
 #include "scene_builder.h"
 
@@ -179,6 +180,8 @@ struct rtg_scene {
   int verbose = 0;
   int window = -1;             // full-feature kernel: records of the program staged in LDS (-1 = as many as fit)
   int ray_lds = 1;             // 0: all slot fields in global memory
+  int sync_full = -1;          // full-feature scenes on the pool-free lock-step kernel (rt_sync_full.h): -1 = when the program holds no BOX record, 0 / 1 = never / always
+  uint32_t n_box = 0;          // BOX records of the flat program
   int lpt = 2;                 // RTG_LPT=0: natural order throughout; 1 / 2 = LptQueue::mode
   int lpt_deep = 4;            // RTG_LPT_DEEP: scatter events at bounce >= this make up a block's cost
   int lpt_shift = 0;           // RTG_LPT_SHIFT: merge cost classes in groups of 1 << shift
@@ -402,6 +405,16 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
     fprintf(stderr, "[rtg] full pool: grid %u x %d threads, %d WG/CU, lds %zu B (program window: %u of %u records), cost-ordered queue after %u chunk(s)\n",
             grid, bt, per_cu, lds, window, s->n_prog, cm.lpt_samples);
   hipLaunchKernelGGL(write_launch_consts, dim3(1), dim3(1), 0, stream, s->d_consts, LaunchConsts{cam, d, cm});
+  if ((s->sync_full > 0 || (s->sync_full < 0 && s->n_box == 0)) && prog == 1) {  // list world without a Bvh: one path per lane, lock-step (rt_sync_full.h)
+    void (*k2)(DevScene, const LaunchConsts*, float*, uint32_t, uint32_t*, unsigned long long*, PoolTuning, float*, uint32_t);
+    if (genb) k2 = tex ? render_full_sync<1, true, COUNT, true> : render_full_sync<1, false, COUNT, true>;
+    else k2 = tex ? render_full_sync<1, true, COUNT, false> : render_full_sync<1, false, COUNT, false>;
+    const size_t lds2 = (size_t)window * 32;
+    e = hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k2, dim3(grid), dim3(bt), lds2, stream, s->dev, (const LaunchConsts*)s->d_consts, d_out, (uint32_t)total_work, queue,
+                       s->d_counters, s->full_tune, s->d_stack, window);
+  } else
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(bt), lds, stream, s->dev, (const LaunchConsts*)s->d_consts, d_out, (uint32_t)total_work, queue,
                      s->d_counters, s->full_tune, s->d_slots, s->d_stack, window);
   e = hipGetLastError();
@@ -752,6 +765,7 @@ int rtg_scene_create(rtg_builder* b, const rtg_id* world, size_t n, int device, 
   s->dev.perlin_perm = (const uint8_t*)s->buffers[5];
   s->dev.n_prog = s->n_prog;
   s->dev.n_mat = s->n_mat;
+  for (const Packet& h : fs.hi) s->n_box += (h.w[3] & 0xffu) == OP_BOX ? 1u : 0u;
   if ((fs.features & (FEAT_ALL | FEAT_BOUNDARY)) == 0) {  // lean program (BOX / SPHERE / END): layout of its LDS image (rt_pool.h)
     std::vector<uint32_t> ops(fs.hi.size()), off(fs.hi.size());
     for (size_t i = 0; i < fs.hi.size(); i++) ops[i] = fs.hi[i].w[3];
@@ -789,6 +803,7 @@ int rtg_scene_set_option(rtg_scene* s, const char* name, int value) {
   else if (k == "lpt_deep") s->lpt_deep = value;
   else if (k == "lpt_shift") s->lpt_shift = std::min(6, std::max(0, value));
   else if (k == "ray_lds") s->ray_lds = value;
+  else if (k == "sync") s->sync_full = value;
   else if (k == "block") s->pool_threads = s->full_threads = value;
   else if (k == "wg_per_cu") s->wg_per_cu = value;
   else if (k == "verbose") s->verbose = value;                  // print launch geometry / schedule statistics to stderr

@@ -291,6 +291,33 @@ def test_every_kernel_variant_and_schedule_gives_the_same_bits(pkg, gpu, oracle,
                          "%s shard %s" % (name, env))
 
 
+@pytest.mark.parametrize("sync", ["0", "1"])
+def test_full_feature_scenes_on_either_schedule(pkg, gpu, oracle, sync, monkeypatch):
+    """Full-feature scenes run on the ray-pool kernel (rt_pool_full.h) or, when the program holds no Bvh, on the lock-step
+    kernel (rt_sync_full.h); `sync` = 1 / 0 forces one or the other for every scene.  Same bits, same counters, same traces."""
+    monkeypatch.setenv("RTG_SYNC", sync)
+    g = np.load(os.path.join(GOLD, "samples.npz"))
+    for name in ("cornell", "volume", "volume_bvh", "cornell_smoke", "checker_scale", "book2", "motion", "simple_light"):
+        sg, cam_g, nx, ny, ns = build_case(pkg, gpu, name)
+        so, cam_o, _, _, _ = build_case(pkg, oracle, name)
+        img_o, st_o = so.par_cast(cam_o, nx, ny, ns, stats=True)
+        img_g, st_g = sg.par_cast(cam_g, nx, ny, ns, stats=True)
+        assert_bit_equal(img_g, img_o, "%s sync=%s" % (name, sync))
+        for k in ("samples", "aabb_tests", "prim_tests", "shaded_hits", "rays", "draws"):
+            assert st_g[k] == st_o[k], (name, sync, k)
+        assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns), img_o, "%s sync=%s (timed variant)" % (name, sync))
+        assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns, rank=1, nranks=3), so.par_cast(cam_o, nx, ny, ns, rank=1, nranks=3), "%s shard" % name)
+        xs, ys, ss = g[name + ".keys"]
+        rgb, info = sg.debug_samples(cam_g, nx, ny, ns, xs, ys, ss, trace_kernel=True)
+        assert np.array_equal(info, g[name + ".info"]), (name, sync)
+        assert_bit_equal(rgb, g[name + ".rgb"], name)
+    # a frame large enough for the cost-ordered queue, and one with more waves than work
+    for name, nx, ny, ns in (("cornell", 144, 128, 12), ("cornell_smoke", 160, 112, 9), ("volume", 17, 9, 3)):
+        sg, cam_g, _, _, _ = build_case(pkg, gpu, name, nx, ny)
+        so, cam_o, _, _, _ = build_case(pkg, oracle, name, nx, ny)
+        assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns), so.par_cast(cam_o, nx, ny, ns), "%s %dx%d sync=%s" % (name, nx, ny, sync))
+
+
 @pytest.mark.parametrize("env", [
     {"RTG_LPT": "0"},                                                    # natural order throughout
     {"RTG_LPT": "1", "RTG_LPT_PHASE1": "2", "RTG_LPT_DEEP": "0"},     # cost-ordered queue, block-major, every scatter counts
