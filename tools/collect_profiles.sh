@@ -5,7 +5,8 @@ cd $R
 # counters + kernel stats of the two production kernels (separate --pmc passes, tools/pmc.sh)
 tools/profile_kernel.sh ${tag}_book1 book1 "render_lean_pool<true, false" 48000000 > $O/profile_book1.log 2>&1
 tools/profile_kernel.sh ${tag}_book2 book2 "render_full_pool<1, true, false" 64000000 --spp 100 > $O/profile_book2.log 2>&1
-for k in book1 book2; do mkdir -p $O/$k; cp gpurun_out/${tag}_$k/* $O/$k/; done
+tools/profile_kernel.sh ${tag}_cornell cornell "render_full_sync<1, false, false" 9000000 > $O/profile_cornell.log 2>&1
+for k in book1 book2 cornell; do mkdir -p $O/$k; cp gpurun_out/${tag}_$k/* $O/$k/; done
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --spp 500 --no-cpu-baseline > $O/bench_500spp.json 2>/dev/null
 python bench.py --bvh sah --no-cpu-baseline > $O/bench_sah.json 2>/dev/null
@@ -18,4 +19,6 @@ python tools/verify_full.py > $O/verify_full.txt 2>&1
 python tools/tail_probe.py > $O/tail_probe.txt 2>&1
 python tools/criterion_scene.py > $O/criterion_scene.txt 2>&1
 tools/ubench/issue_rate > $O/issue_rate.txt 2>&1
+python tools/libm_exhaustive_gpu.py > $O/libm_exhaustive_gpu.txt 2>&1
+python -m pytest tests -m gpu -q --timeout=120 > $O/pytest_gpu.log 2>&1
 ls -la $O
