@@ -208,7 +208,7 @@ def main():
         # events on the launch stream; peak = 256 CUs x 4 SIMDs x shader clock / issue cycles per wave64 instruction.
         # tools/roofline.py recomputes the same object from profiles/<tag>/pmc_summary.json + kernel_stats.csv.
         from rtiow_rust_amd import roofline as rl
-        kernel_name = ("rtg::render_lean_pool" if info_lean else "rtg::render_full_pool")
+        kernel_name = {"book1": "rtg::render_lean_pool", "book2": "rtg::render_full_pool", "cornell": "rtg::render_full_sync"}[args.workload]
         kernel_s = avg_kernel_ms * 1e-3
         rank_samples = px_rank * spp
         pmc, pmc_path = rl.find_profile(ROOT, args.workload if args.bvh == "reference" else args.workload + "_" + args.bvh)
