@@ -6,7 +6,9 @@ stream and its float conversions).  tests/golden/ref_rttnw_final_200.npz is that
 what IS decidable: our render of the same scene correlates with the reference's picture where the construction randomness shows
 (floor, sphere cube) only if the emulated SmallRng stream is the real one -- any other construction seed drops the floor
 correlation from 0.91 to ~0.5.  This pins small_rng.py (`seed_from_u64`, Pcg64Mcg, gen::<f32>(), gen_range) and the scene
-transliteration against an output of the reference, which the recorded-but-unverified KATs could not."""
+transliteration against an output of the reference, which the recorded-but-unverified KATs could not.
+(Levels are NOT compared: bright regions agree within 1-4 of 255, but the JPEG's dark regions sit ~10 levels above ours -- the
+README does not say which revision, light or tone curve produced it -- so the test uses correlation, which an offset cannot fake.)"""
 import os
 
 import numpy as np
