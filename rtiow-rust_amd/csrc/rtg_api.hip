@@ -188,7 +188,7 @@ struct rtg_scene {
   int lpt_phase1 = 0;          // RTG_LPT_PHASE1: chunks in natural order, 0 = n_chunks / 8 clamped to [2, 8]
   // 3 = ray-pool kernels (rt_pool.h / rt_pool_full.h), 1 = one-lane-per-pixel baseline (rt_trace.h) for every scene
   int kernel_version = 3;
-  PoolTuning pool_tune{36, 16, 32, 16, 16, 40};  // lean ray-pool kernel
+  PoolTuning pool_tune{40, 16, 24, 16, 16, 40};  // lean ray-pool kernel (refill_min, sphere_min, box_leave: profiles/r02_e_final/lean_knob_sweep.txt)
   PoolTuning full_tune{20, 16, 32, 16, 16, 40};  // full-feature kernel (a service there also has hit records to move)
   int wg_per_cu = 0;                       // 0 = ask the occupancy API
   int full_threads = 0;                    // full-feature pool kernel: 0 = the variant's maximum (RTG_BLOCK overrides)
