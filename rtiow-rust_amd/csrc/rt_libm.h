@@ -19,7 +19,7 @@ __device__ __forceinline__ uint32_t gl_asuint(float f) { return __float_as_uint(
 __device__ __forceinline__ float gl_asfloat(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ uint64_t gl_asuint64(double f) { return (uint64_t)__double_as_longlong(f); }
 __device__ __forceinline__ double gl_asdouble(uint64_t u) { return __longlong_as_double((long long)u); }
-// out of line: rare on the hot path (one ln per medium evaluation, one powf per glass hit, sin only under a checker texture)
+// ln and sin out of line: rare on the hot path (one ln per medium evaluation, sin only under a checker texture)
 #define GL_FN __device__ __attribute__((noinline))
 #define GL_TAB __device__
 #define GL_FMA(a, b, c) __builtin_fma((a), (b), (c))
@@ -83,7 +83,7 @@ GL_FN float rt_logf(float x) {
 }
 
 // glibc e_powf.c with y = 5.0f (schlick, material.rs:145): log2 via a 16-entry table + degree-5 polynomial, exp2 via a 32-entry table
-GL_FN float rt_pow5f(float x) {
+__device__ __forceinline__ float rt_pow5f(float x) {  // inline: one per glass hit in the SCATTER pass (out of line: C2 +1 %)
   uint32_t sign_bias = 0u, ix = gl_asuint(x);
   if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
     if (2u * ix - 1u >= 2u * 0x7f800000u - 1u) {  // x is +-0, +-inf or nan; y = 5 is a positive odd integer
