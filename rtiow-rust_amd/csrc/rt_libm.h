@@ -83,7 +83,10 @@ GL_FN float rt_logf(float x) {
 }
 
 // glibc e_powf.c with y = 5.0f (schlick, material.rs:145): log2 via a 16-entry table + degree-5 polynomial, exp2 via a 32-entry table
-__device__ __forceinline__ float rt_pow5f(float x) {  // inline: one per glass hit in the SCATTER pass (out of line: C2 +1 %)
+// (a template so that the lean kernel's SCATTER pass can take it inline -- C2 7.97 -> 7.90 ms -- while the full-feature kernels,
+// which sit at the 128-VGPR limit, call the out-of-line copy)
+template <bool INLINE>
+__device__ __attribute__((always_inline)) float rt_pow5f_body(float x) {
   uint32_t sign_bias = 0u, ix = gl_asuint(x);
   if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
     if (2u * ix - 1u >= 2u * 0x7f800000u - 1u) {  // x is +-0, +-inf or nan; y = 5 is a positive odd integer
@@ -130,6 +133,9 @@ __device__ __forceinline__ float rt_pow5f(float x) {  // inline: one per glass h
   yy = yy * s;
   return (float)yy;
 }
+
+GL_FN float rt_pow5f(float x) { return rt_pow5f_body<false>(x); }
+__device__ __forceinline__ float rt_pow5f_inline(float x) { return rt_pow5f_body<true>(x); }
 
 // glibc s_sinf.c (ARM optimized-routines sinf): double-precision polynomials, table-driven reduction for |x| >= 120
 GL_FN float gl_sinf_poly(double x, double x2, uint32_t neg, uint32_t n) {  // neg: the coefficient set of the negated cosine

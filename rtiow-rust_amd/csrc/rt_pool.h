@@ -596,7 +596,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
             bool refracted = disc > 0.f;
             if (refracted) {
               nd = vsub(smul(ni_over_nt, vsub(uv, smul(dt, outward))), smul(__builtin_sqrtf(disc), outward));
-              refracted = rng.gen_f32() >= schlick(cosine, param);  // material.rs:97: draw only if Some
+              refracted = rng.gen_f32() >= schlick<true>(cosine, param);  // material.rs:97: draw only if Some
             }
             if (!refracted) nd = reflect(sd, hn);
             att = splat(1.f);

@@ -465,10 +465,11 @@ RT_DEV V3 material_texture(const DevScene& sc, uint4 mlo, uint4 mhi, V3 p) {
   return mk(u2f(mlo.x), u2f(mlo.y), u2f(mlo.z));
 }
 
+template <bool INLINE_POW = false>
 RT_DEV float schlick(float cos, float ref_idx) {  // material.rs:142-146
   float r0 = (1.f - ref_idx) / (1.f + ref_idx);
   r0 = r0 * r0;
-  return r0 + (1.f - r0) * rt_pow5f(1.f - cos);
+  return r0 + (1.f - r0) * (INLINE_POW ? rt_pow5f_inline(1.f - cos) : rt_pow5f(1.f - cos));
 }
 
 // camera.rs:52-63
