@@ -4,8 +4,13 @@
 //
 // Differences from the lean kernel:
 //  * the hit record (p, normal, material) is built at hit time and carried in registers, because it
-//    has to travel back through the enclosing POPs (object.rs:279-282,365-369); at END it is written
-//    to the path slot (7 dwords) instead of (best, best_pc);
+//    has to travel back through the enclosing POPs (object.rs:279-282,365-369);
+//  * paths have no home slot: their state MOVES through three dense per-wave stacks in global memory -- T (rays to
+//    traverse: origin, direction, time, strength, bounces, sample, pixel), S and X (finished rays to shade without / with
+//    a texture lookup: hit record, direction, time, draws made, strength, bounces, sample, pixel).  Every push goes to
+//    consecutive positions ([field][position] rows, so a wave's push is whole cache lines) and every pop takes the top:
+//    what was written last is read next, from L2.  The lanes carry strength / bounces / sample / pixel in registers
+//    while they traverse;
 //  * every non-BOX record (SPHERE, RECT, PUSH, POP, MEDIUM) is a "slow op": lanes park on it and a slow
 //    pass executes one record per parked lane once enough lanes wait (or no BOX lane is left);
 //  * the transform stack (<= 4 saved rays) lives in a per-wave, lane-interleaved global scratch;
@@ -22,17 +27,18 @@ namespace rtg {
 #ifndef RT_FULL_POOL_SLOTS
 #define RT_FULL_POOL_SLOTS 160  // 128: gather points and slow passes run short of waiting lanes (book-2 +15 %); 192: +2.5 %
 #endif
-constexpr uint32_t FPOOL = RT_FULL_POOL_SLOTS;  // path slots per wave of the full-feature kernel (21 dwords each)
-constexpr uint32_t FPOOL_FIELDS = 21;
-enum FullPoolField : uint32_t {
-  FF_O = 0, FF_D = 3, FF_TIME = 6, FF_HITMAT = 7, FF_P = 8, FF_N = 11, FF_STRENGTH = 14, FF_BOUNCES = 17, FF_SAMPLE = 18, FF_XY = 19,
-  FF_EVDRAWS = 20,
+constexpr uint32_t FPOOL = RT_FULL_POOL_SLOTS;  // paths in flight per wave of the full-feature kernel = capacity of each stack
+enum FullTField : uint32_t {  // T stack: a ray ready to traverse (the *_TRACE rows only exist for the instrumented variant)
+  TQ_O = 0, TQ_D = 3, TQ_TIME = 6, TQ_STRENGTH = 7, TQ_BOUNCES = 10, TQ_SAMPLE = 11, TQ_XY = 12, TQ_TRACE = 13, TQ_FIELDS = 16,
 };
+enum FullSField : uint32_t {  // S / X stacks: a finished ray with its hit record
+  SQ_P = 0, SQ_N = 3, SQ_D = 6, SQ_TIME = 9, SQ_HITMAT = 10, SQ_EVDRAWS = 11, SQ_STRENGTH = 12, SQ_BOUNCES = 15, SQ_SAMPLE = 16,
+  SQ_XY = 17, SQ_TRACE = 18, SQ_FIELDS = 21,
+};
+constexpr uint32_t FPOOL_FIELDS = TQ_FIELDS + 2 * SQ_FIELDS;  // dwords of stack space per path in flight (T, S, X)
 
-// LDS = the first `window` program records (all of them when the program fits, 0 = none) + the lists
-inline size_t full_pool_lds_bytes(uint32_t window, uint32_t waves) {
-  return (size_t)window * 32 + (((size_t)waves * FPOOL * 3 * 2 + 15) & ~(size_t)15);  // T-, S- and X-list (u16 slot ids)
-}
+// LDS = the first `window` program records (all of them when the program fits, 0 = none)
+inline size_t full_pool_lds_bytes(uint32_t window, uint32_t /*waves*/) { return (size_t)window * 32; }
 
 // draw `idx` (0-based) of the stream (seed, pixel, sample, event): word idx%4 of Philox block idx/4
 __device__ __attribute__((noinline)) float event_draw_f32(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t event, uint32_t idx) {
@@ -53,6 +59,67 @@ __device__ __attribute__((noinline)) float event_draw_f32(uint64_t seed, uint32_
 #define RT_FULL_TEX_THREADS 1024  // the textured variant wants ~142 VGPRs; capped at 128 it spills ~25 of them to scratch but
                                   // runs 16 instead of 12 waves per CU: measured 4 % faster on book-2 (768 = no spills)
 #endif
+// ---- stack access: `qr` = the wave's stack space
+RT_DEV uint32_t f2u(float f) { return __float_as_uint(f); }
+typedef __amdgpu_buffer_rsrc_t QueueRsrc;
+constexpr uint32_t SQ_BASE = TQ_FIELDS;  // first row of the S (+X) stacks
+RT_DEV QueueRsrc make_queue_rsrc(uint32_t* wave_base) {
+  // raw buffer (stride 0, bounds = the wave's stack space in bytes; word 3 = gfx9 raw-buffer format bits)
+  return __builtin_amdgcn_make_buffer_rsrc(wave_base, 0, FPOOL * FPOOL_FIELDS * 4u, 0x00020000);
+}
+#define RT_IN_LDS(pc_) (PROG == 1 || (PROG == 2 && (pc_) < win_bytes))
+#define RT_FETCH_LO(pc_) (RT_IN_LDS(pc_) ? *reinterpret_cast<const uint4*>(s_bytes + (pc_)) : sc.lo[(pc_) >> 4])
+#define RT_FETCH_HI(pc_) (RT_IN_LDS(pc_) ? *reinterpret_cast<const uint4*>(s_bytes + win_bytes + (pc_)) : fetch_hi_global(sc, (pc_) >> 4))
+// Stack records are addressed through ONE buffer resource per wave (`qr`: base = the wave's stack space, in SGPRs) with the
+// position as the only VGPR of an access and the row as a constant offset -- no 64-bit address arithmetic, no address registers.
+#define Q_ROW(base_, f_) (((base_) + (f_)) * FPOOL * 4u)  /* byte offset of a row */
+#define Q_LD(row_, i_) __builtin_amdgcn_raw_buffer_load_b32(qr, (i_) * 4u + ((row_) & 4095u), (row_) & ~4095u, 0)
+#define Q_ST(row_, i_, v_) __builtin_amdgcn_raw_buffer_store_b32((v_), qr, (i_) * 4u + ((row_) & 4095u), (row_) & ~4095u, 0)
+#define TQ_LD_U(f_, i_) Q_LD(Q_ROW(0u, f_), i_)
+#define TQ_LD_F(f_, i_) u2f(TQ_LD_U(f_, i_))
+#define TQ_ST_U(f_, i_, v_) Q_ST(Q_ROW(0u, f_), i_, (uint32_t)(v_))
+#define TQ_ST_F(f_, i_, v_) Q_ST(Q_ROW(0u, f_), i_, f2u(v_))
+#define SQ_LD_U(f_, i_) Q_LD(Q_ROW(SQ_BASE, f_), i_)
+#define SQ_LD_F(f_, i_) u2f(SQ_LD_U(f_, i_))
+#define SQ_ST_U(f_, i_, v_) Q_ST(Q_ROW(SQ_BASE, f_), i_, (uint32_t)(v_))
+#define SQ_ST_F(f_, i_, v_) Q_ST(Q_ROW(SQ_BASE, f_), i_, f2u(v_))
+constexpr uint32_t XQ = SQ_FIELDS * FPOOL;  // X stack = positions XQ.. of the S rows: hits on checker / Perlin materials
+
+// Push finished rays onto S or X: consecutive positions (wave-uniform call; `fin` selects the lanes).
+// hmat bit 31 = the hit material reads a non-constant texture (F_TEXTURED of the winning record): such hits are shaded in
+// their own passes, so the Perlin / checker code is issued for 64 textured hits at a time instead of in every pass that
+// happens to hold one.
+template <bool TEX, bool TRACE>
+RT_DEV void full_push_finished(const QueueRsrc qr, uint32_t& s_count, uint32_t& x_count, const bool fin, const V3 fhp, const V3 fhn,
+                               const uint32_t fhmat, const V3 fd, const float ftime, const uint32_t fev, const V3 fstrength,
+                               const uint32_t fbounces, const uint32_t fsample, const uint32_t fxy, const bool trace,
+                               const uint32_t ft0, const uint32_t ft1, const uint32_t ft2) {
+  const bool to_x = TEX && fin && fhmat != NO_HIT && (fhmat >> 31) != 0u;
+  const uint64_t m_fin = __builtin_amdgcn_ballot_w64(fin && !to_x), m_x = __builtin_amdgcn_ballot_w64(to_x);
+  if (fin) {
+    const uint32_t i = to_x ? XQ + x_count + lane_rank(m_x) : s_count + lane_rank(m_fin);
+    SQ_ST_U(SQ_HITMAT, i, fhmat == NO_HIT ? NO_HIT : (fhmat & 0x7fffffffu));
+    SQ_ST_F(SQ_P, i, fhp.x), SQ_ST_F(SQ_P + 1, i, fhp.y), SQ_ST_F(SQ_P + 2, i, fhp.z);
+    SQ_ST_F(SQ_N, i, fhn.x), SQ_ST_F(SQ_N + 1, i, fhn.y), SQ_ST_F(SQ_N + 2, i, fhn.z);
+    SQ_ST_F(SQ_D, i, fd.x), SQ_ST_F(SQ_D + 1, i, fd.y), SQ_ST_F(SQ_D + 2, i, fd.z);
+    SQ_ST_F(SQ_TIME, i, ftime);
+    SQ_ST_U(SQ_EVDRAWS, i, fev);
+    SQ_ST_F(SQ_STRENGTH, i, fstrength.x), SQ_ST_F(SQ_STRENGTH + 1, i, fstrength.y), SQ_ST_F(SQ_STRENGTH + 2, i, fstrength.z);
+    SQ_ST_U(SQ_BOUNCES, i, fbounces), SQ_ST_U(SQ_SAMPLE, i, fsample), SQ_ST_U(SQ_XY, i, fxy);
+    if (TRACE && trace) SQ_ST_U(SQ_TRACE, i, ft0), SQ_ST_U(SQ_TRACE + 1, i, ft1), SQ_ST_U(SQ_TRACE + 2, i, ft2);
+  }
+  s_count += (uint32_t)__builtin_popcountll(m_fin);
+  x_count += (uint32_t)__builtin_popcountll(m_x);
+}
+
+// A wave-uniform pointer derived from threadIdx (the wave's own memory): readfirstlane tells the compiler it is uniform
+template <typename T>
+RT_DEV T* uniform_ptr(T* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
+}
+
 // GENB: the scene holds a ConstantMedium whose boundary is an object graph (F_GENERAL_BOUNDARY, e.g. the book's smoke
 // boxes: ConstantMedium<Translate<RotateY<And<...>>>>, object.rs:533-575).  Its two boundary queries
 // (`boundary.hit(f32::MIN..f32::MAX)`, then `boundary.hit(t1 + 0.0001..f32::MAX)`, object.rs:551-552) run THROUGH THE SAME
@@ -75,7 +142,6 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   constexpr uint32_t OP_SLOW_LAST = GENB ? (uint32_t)OP_BEND : (uint32_t)OP_PRISM;  // records a slow pass executes
   constexpr uint32_t STACK_LEVELS = GENB ? 2 * MAX_XFORM_DEPTH : MAX_XFORM_DEPTH;   // a boundary stream nests below the medium's own wrappers
   constexpr bool USE_LDS = PROG != 0;
-  const uint32_t staged = USE_LDS ? 2u * window : 0u;  // uint4 units; pc = 16 r, hi[] of the window at +16 window
   const uint32_t win_bytes = 16u * window;
   if (USE_LDS) {
     for (uint32_t i = threadIdx.x; i < window; i += blockDim.x) {
@@ -87,23 +153,14 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
     }
   }
   const char* s_bytes = reinterpret_cast<const char*>(s_mem);
-#define RT_IN_LDS(pc_) (PROG == 1 || (PROG == 2 && (pc_) < win_bytes))
-#define RT_FETCH_LO(pc_) (RT_IN_LDS(pc_) ? *reinterpret_cast<const uint4*>(s_bytes + (pc_)) : sc.lo[(pc_) >> 4])
-#define RT_FETCH_HI(pc_) (RT_IN_LDS(pc_) ? *reinterpret_cast<const uint4*>(s_bytes + win_bytes + (pc_)) : fetch_hi_global(sc, (pc_) >> 4))
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, n_waves = blockDim.x >> 6;
   const size_t gwave = (size_t)blockIdx.x * n_waves + wave;
-  uint32_t* slot = g_slots + gwave * (FPOOL * FPOOL_FIELDS);
-  float* slotf = reinterpret_cast<float*>(slot);
-  float* stack = g_stack + gwave * (STACK_LEVELS * 6 * 64);  // [level][component][lane]
-  uint16_t* tlist = reinterpret_cast<uint16_t*>(s_mem + staged) + wave * (3u * FPOOL);
-  uint16_t* slist = tlist + FPOOL;  // finished rays whose material needs no texture lookup (and slots without a ray)
-  uint16_t* xlist = slist + FPOOL;  // finished rays that hit a checker / Perlin textured material
-#define SLOT_U(f_, j_) slot[(f_)*FPOOL + (j_)]
-#define SLOT_F(f_, j_) slotf[(f_)*FPOOL + (j_)]
-  for (uint32_t j = lane; j < FPOOL; j += 64u) {
-    SLOT_U(FF_HITMAT, j) = SLOT_NEED_PIXEL;
-    slist[j] = (uint16_t)j;
-  }
+  // (wave-uniform, but derived from threadIdx: without the readfirstlane the compiler keeps these in VGPRs and loops over the
+  // "different" resources of a wave at every access)
+  uint32_t* tq = uniform_ptr(g_slots + gwave * (FPOOL * FPOOL_FIELDS));
+  const QueueRsrc qr = make_queue_rsrc(tq);                  // rows: T, then S (+X), then G (+R) -- see Q_ROW
+  float* stack = uniform_ptr(g_stack + gwave * (STACK_LEVELS * 6 * 64));  // [level][component][lane]; level 0 rides in registers
+  for (uint32_t j = lane; j < FPOOL; j += 64u) SQ_ST_U(SQ_HITMAT, j, SLOT_NEED_PIXEL);  // FPOOL entries that ask for a work item
   __syncthreads();
 
   const float t_near = load_const(&lc->P.t_near);
@@ -113,7 +170,6 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   bool exhausted = false;
 
   // ---- per-lane traversal state ---------------------------------------------------------------
-  uint32_t my_slot = 0;
   bool have_ray = false;
   V3 o = mk(0.f, 0.f, 0.f), d = o, inv = o;
   float time = 0.f, best = F32_MAX;
@@ -122,20 +178,18 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   V3 hp = o, hn = o;                 // hit record (object.rs:61-71), in the space of wrapper depth `tag`
   uint32_t hmat = NO_HIT;            // NO_HIT = None
   uint32_t depth = 0, tag = 0, nhits = 0, root_hits = 0, ev_draws = 0;
-  uint32_t r_pixel = 0, r_sample = 0, r_event = 0;  // RNG stream of this ray's event (media)
+  uint32_t r_xy = 0, r_sample = 0, r_bounces = 0;  // the path's pixel (x | row << 16), sample and bounce count: its RNG stream for media
+  V3 r_strength = o;                                // the path's strength rides along (lib.rs:77)
+  V3 sv_o = o, sv_d = o;                            // level 0 of the transform stack (the ray outside the outermost wrapper)
   uint32_t bmode = 0;                                // GENB: 0 = main walk, 1 / 2 = inside a boundary stream, query 1 / 2
   float t_lo = t_near, b_saved = 0.f, b_t1 = 0.f;    // GENB: lower end of the current range; the main walk's best; query 1's t
   Counts cnt = {0, 0, 0, 0};
   uint32_t total_draws = 0;
   uint32_t* tr_out = nullptr;  // per-sample trace of the instrumented variant (rt_pool.h)
-  uint32_t* tr_slot = nullptr;
-  uint32_t tr_a0 = 0, tr_p0 = 0;
-  if (COUNT) {
-    tr_out = reinterpret_cast<uint32_t*>(counters[30]);
-    if (tr_out) tr_slot = reinterpret_cast<uint32_t*>(counters[31]) + gwave * (FPOOL * 3u);
-  }
+  uint32_t tr_a0 = 0, tr_p0 = 0, tr_d = 0, tr_a = 0, tr_p = 0;  // the path's running draws / Aabb tests / primitive tests
+  if (COUNT) tr_out = reinterpret_cast<uint32_t*>(counters[30]);
   uint32_t n_box_it = 0, n_box_lanes = 0, n_slow_it = 0, n_slow_lanes = 0, n_shade = 0, n_shade_lanes = 0, n_refill = 0;
-  unsigned long long t_shade = 0, t_serv = 0, t_box = 0, t_slow = 0, t_mark = 0, t_mark2 = 0;  // COUNT: s_memtime shares
+  unsigned long long t_shade = 0, t_serv = 0, t_box = 0, t_slow = 0, t_refill = 0, t_fin = 0, n_serv = 0, t_mark = 0, t_mark2 = 0;  // COUNT: s_memtime shares
 
 #include "rt_full_ops.inc"
 
@@ -145,32 +199,23 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
     const uint64_t m_slow = __builtin_amdgcn_ballot_w64(op >= OP_SPHERE && op <= OP_SLOW_LAST);
     const uint32_t n_busy = (uint32_t)__builtin_popcountll(m_box | m_slow);
     // ============================== SERVICE ======================================================
-    if (64u - n_busy >= tune.refill_min || n_busy == 0) {
+    // due when enough lanes are idle AND the service can do something for them: rays to hand out (T), or a full shade pass once
+    // the lanes that stand at END are pushed.  (With rays waiting in S and X for company, "idle lanes" alone would call it
+    // after every traversal step of a starved wave.)
+    const uint32_t n_fin = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op == OP_END));
+    const bool can_serve = t_count != 0u || s_count + n_fin >= 64u || (TEX && x_count + n_fin >= 64u);
+    if ((64u - n_busy >= tune.refill_min && can_serve) || n_busy == 0) {
       if (COUNT) t_mark = RT_TICK();
-      {  // (1) finish
+      {  // (1) finish (depth is 0 again, so o / d are the ray's own)
         const bool fin = have_ray && op == OP_END;
-        // hmat bit 31 = the hit material reads a non-constant texture (F_TEXTURED of the winning record):
-        // such hits are shaded in their own passes, so the Perlin / checker code is issued for 64 textured
-        // hits at a time instead of in every pass that happens to hold one
-        const bool to_x = TEX && fin && hmat != NO_HIT && (hmat >> 31) != 0u;
-        const uint64_t m_fin = __builtin_amdgcn_ballot_w64(fin && !to_x), m_x = __builtin_amdgcn_ballot_w64(to_x);
-        if (fin) {
-          SLOT_U(FF_HITMAT, my_slot) = hmat == NO_HIT ? NO_HIT : (hmat & 0x7fffffffu);
-          SLOT_F(FF_P, my_slot) = hp.x, SLOT_F(FF_P + 1, my_slot) = hp.y, SLOT_F(FF_P + 2, my_slot) = hp.z;
-          SLOT_F(FF_N, my_slot) = hn.x, SLOT_F(FF_N + 1, my_slot) = hn.y, SLOT_F(FF_N + 2, my_slot) = hn.z;
-          SLOT_U(FF_EVDRAWS, my_slot) = ev_draws;
-          if (COUNT && tr_slot)
-            tr_slot[my_slot] += ev_draws, tr_slot[FPOOL + my_slot] += cnt.aabb - tr_a0, tr_slot[2u * FPOOL + my_slot] += cnt.prim - tr_p0;
-          if (to_x) xlist[x_count + lane_rank(m_x)] = (uint16_t)my_slot;
-          else slist[s_count + lane_rank(m_fin)] = (uint16_t)my_slot;
-          have_ray = false;
-        }
-        s_count += (uint32_t)__builtin_popcountll(m_fin);
-        x_count += (uint32_t)__builtin_popcountll(m_x);
+        full_push_finished<TEX, COUNT>(qr, s_count, x_count, fin, hp, hn, hmat, d, time, ev_draws, r_strength, r_bounces, r_sample, r_xy,
+                                       tr_out != nullptr, tr_d + ev_draws, tr_a + (cnt.aabb - tr_a0), tr_p + (cnt.prim - tr_p0));
+        if (fin) have_ray = false;
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      if (COUNT) t_fin += RT_TICK() - t_mark, n_serv++;
       // (2) shade
-      auto shade_pass = [&](auto textured_tag, uint16_t* list, uint32_t& count) {
+      auto shade_pass = [&](auto textured_tag, const uint32_t q0, uint32_t& count) {  // q0 = 0 (S) or XQ (X)
         constexpr bool TEXTURED = decltype(textured_tag)::value;
         constexpr uint32_t PASS_FEAT = TEXTURED ? FEAT : (FEAT & ~FEAT_TEXTURE);
         const DevParams P = load_const(&lc->P);
@@ -179,7 +224,8 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         const uint32_t take = count < 64u ? count : 64u;
         count -= take;
         if (COUNT) n_shade++, n_shade_lanes += take, t_mark2 = RT_TICK();
-        uint32_t st = ST_DEAD, j = 0;
+        uint32_t st = ST_DEAD;
+        uint32_t trd = 0, tra = 0, trp = 0;
         V3 so = mk(0.f, 0.f, 0.f), sd = so, strength = so;
         // no accum field: it is +0 whenever it is read (rt_pool.h PoolField; the host only routes scenes
         // here whose path strength stays finite and non-negative)
@@ -188,38 +234,38 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         uint32_t bounces = 0, s = 0, x = 0, row = 0;
         bool lpt_on = false;
         if (lane < take) {
-          j = list[count + lane];
-          const uint32_t hm = SLOT_U(FF_HITMAT, j);
+          const uint32_t j = q0 + count + lane;  // pop: the top `take` entries
+          const uint32_t hm = SQ_LD_U(SQ_HITMAT, j);
           if (hm == SLOT_NEED_PIXEL) {
             st = ST_NEED_PIXEL;
           } else {
             // The texture value is fetched FIRST, while almost nothing of this pass is live: texture_eval
             // (Perlin turbulence / checker) is an out-of-line call and everything live across it adds to
             // the kernel's register count.
-            const V3 p = mk(SLOT_F(FF_P, j), SLOT_F(FF_P + 1, j), SLOT_F(FF_P + 2, j));
+            const V3 p = mk(SQ_LD_F(SQ_P, j), SQ_LD_F(SQ_P + 1, j), SQ_LD_F(SQ_P + 2, j));
             uint4 mlo = make_uint4(0, 0, 0, 0), mhi = make_uint4(0, 0, 0, 0);
             V3 texval = mk(0.f, 0.f, 0.f);
             if (hm != NO_HIT) {
               mlo = sc.mat[2 * hm], mhi = sc.mat[2 * hm + 1];
               texval = material_texture<PASS_FEAT>(sc, mlo, mhi, p);  // = albedo / emission colour for constant textures
             }
-            so = mk(SLOT_F(FF_O, j), SLOT_F(FF_O + 1, j), SLOT_F(FF_O + 2, j));
-            sd = mk(SLOT_F(FF_D, j), SLOT_F(FF_D + 1, j), SLOT_F(FF_D + 2, j));
-            stime = SLOT_F(FF_TIME, j);
-            strength = mk(SLOT_F(FF_STRENGTH, j), SLOT_F(FF_STRENGTH + 1, j), SLOT_F(FF_STRENGTH + 2, j));
-            bounces = SLOT_U(FF_BOUNCES, j), s = SLOT_U(FF_SAMPLE, j);
-            const uint32_t xy = SLOT_U(FF_XY, j);
+            sd = mk(SQ_LD_F(SQ_D, j), SQ_LD_F(SQ_D + 1, j), SQ_LD_F(SQ_D + 2, j));
+            stime = SQ_LD_F(SQ_TIME, j);
+            strength = mk(SQ_LD_F(SQ_STRENGTH, j), SQ_LD_F(SQ_STRENGTH + 1, j), SQ_LD_F(SQ_STRENGTH + 2, j));
+            bounces = SQ_LD_U(SQ_BOUNCES, j), s = SQ_LD_U(SQ_SAMPLE, j);
+            if (COUNT && tr_out) trd = SQ_LD_U(SQ_TRACE, j), tra = SQ_LD_U(SQ_TRACE + 1, j), trp = SQ_LD_U(SQ_TRACE + 2, j);
+            const uint32_t xy = SQ_LD_U(SQ_XY, j);
             x = xy & 0xffffu, row = xy >> 16;
             // ---------------- color() loop body, lib.rs:73-97 ----------------
             SampleRng rng;
             rng.init(seed, (P.ny - 1u - row) * P.nx + x, s);
             rng.set_event(bounces + 1u);
-            rng.seek(SLOT_U(FF_EVDRAWS, j));  // continue after the medium draws of this event's traversal
+            rng.seek(SQ_LD_U(SQ_EVDRAWS, j));  // continue after the medium draws of this event's traversal
             bool ended = true;
             V3 result = mk(0.f, 0.f, 0.f);
             if (hm != NO_HIT) {
               if (COUNT) cnt.shaded++;
-              const V3 n = mk(SLOT_F(FF_N, j), SLOT_F(FF_N + 1, j), SLOT_F(FF_N + 2, j));
+              const V3 n = mk(SQ_LD_F(SQ_N, j), SQ_LD_F(SQ_N + 1, j), SQ_LD_F(SQ_N + 2, j));
               const uint32_t kind = mhi.w & 0xffu;
               const float param = u2f(mlo.w);
               V3 emitted = mk(0.f, 0.f, 0.f);
@@ -280,13 +326,13 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
               }
             }
             if (COUNT) total_draws += rng.draws;
-            if (COUNT && tr_slot) tr_slot[j] += rng.draws;
+            if (COUNT) trd += rng.draws;
             if (ended) {
               float* sp = cm.scratch + 3ull * ((size_t)s * cm.pix_work + pixel_to_work(P, x, row));
               RT_SCRATCH_STORE(sp, result);
               if (COUNT && tr_out) {
                 uint32_t* tp = tr_out + 4ull * ((size_t)s * cm.pix_work + pixel_to_work(P, x, row));
-                tp[0] = bounces, tp[1] = tr_slot[j], tp[2] = tr_slot[FPOOL + j], tp[3] = tr_slot[2u * FPOOL + j];
+                tp[0] = bounces, tp[1] = trd, tp[2] = tra, tp[3] = trp;
               }
               s++;
               st = (s == P.ns || s % cm.chunk == 0u) ? ST_NEED_PIXEL : ST_GEN;
@@ -339,19 +385,20 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           get_ray(cam, u, v, rng, so, sd, stime);
           accum = mk(0.f, 0.f, 0.f), strength = splat(1.f), bounces = 0;
           if (COUNT) total_draws += rng.draws;
-          if (COUNT && tr_slot) tr_slot[j] = rng.draws, tr_slot[FPOOL + j] = 0u, tr_slot[2u * FPOOL + j] = 0u;
+          if (COUNT) trd = rng.draws, tra = 0u, trp = 0u;
           st = ST_TRAV;
         }
         const bool live = st == ST_TRAV;
         const uint64_t m_live = __builtin_amdgcn_ballot_w64(live);
-        if (live) {
-          SLOT_F(FF_O, j) = so.x, SLOT_F(FF_O + 1, j) = so.y, SLOT_F(FF_O + 2, j) = so.z;
-          SLOT_F(FF_D, j) = sd.x, SLOT_F(FF_D + 1, j) = sd.y, SLOT_F(FF_D + 2, j) = sd.z;
-          SLOT_F(FF_TIME, j) = stime;
-          SLOT_F(FF_STRENGTH, j) = strength.x, SLOT_F(FF_STRENGTH + 1, j) = strength.y, SLOT_F(FF_STRENGTH + 2, j) = strength.z;
-          SLOT_U(FF_BOUNCES, j) = bounces, SLOT_U(FF_SAMPLE, j) = s;
-          SLOT_U(FF_XY, j) = x | (row << 16);
-          tlist[t_count + lane_rank(m_live)] = (uint16_t)j;
+        if (live) {  // push onto T
+          const uint32_t i = t_count + lane_rank(m_live);
+          TQ_ST_F(TQ_O, i, so.x), TQ_ST_F(TQ_O + 1, i, so.y), TQ_ST_F(TQ_O + 2, i, so.z);
+          TQ_ST_F(TQ_D, i, sd.x), TQ_ST_F(TQ_D + 1, i, sd.y), TQ_ST_F(TQ_D + 2, i, sd.z);
+          TQ_ST_F(TQ_TIME, i, stime);
+          TQ_ST_F(TQ_STRENGTH, i, strength.x), TQ_ST_F(TQ_STRENGTH + 1, i, strength.y), TQ_ST_F(TQ_STRENGTH + 2, i, strength.z);
+          TQ_ST_U(TQ_BOUNCES, i, bounces), TQ_ST_U(TQ_SAMPLE, i, s);
+          TQ_ST_U(TQ_XY, i, x | (row << 16));
+          if (COUNT && tr_out) TQ_ST_U(TQ_TRACE, i, trd), TQ_ST_U(TQ_TRACE + 1, i, tra), TQ_ST_U(TQ_TRACE + 2, i, trp);
           if (COUNT) cnt.rays++;
         }
         t_count += (uint32_t)__builtin_popcountll(m_live);
@@ -359,37 +406,44 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         if (COUNT) t_shade += RT_TICK() - t_mark2;
       };
-      const bool starving = t_count == 0 && n_busy == 0;
-      while (s_count >= 64u || (s_count > 0 && starving)) shade_pass(std::false_type{}, slist, s_count);
-      if (TEX)
-        while (x_count >= 64u || (x_count > 0 && starving && t_count == 0)) shade_pass(std::true_type{}, xlist, x_count);
-      {  // (3) refill
+      for (;;) {  // full passes first; partial ones only when the lanes would have nothing to traverse (ONE call site per pass kind)
+        const bool any_part = n_busy == 0 && t_count == 0;
+        uint32_t which = s_count >= 64u ? 1u : (TEX && x_count >= 64u) ? 2u : 0u;
+        if (which == 0u && any_part) which = s_count ? 1u : (TEX && x_count) ? 2u : 0u;
+        if (which == 0u) break;
+        if (which == 1u) shade_pass(std::false_type{}, 0u, s_count);
+        else if (TEX) shade_pass(std::true_type{}, XQ, x_count);
+      }
+      if (COUNT) t_mark2 = RT_TICK();
+      {  // (3) refill from T
         const uint64_t m_idle = __builtin_amdgcn_ballot_w64(!have_ray);
         const uint32_t n_idle = (uint32_t)__builtin_popcountll(m_idle);
         const uint32_t got = n_idle < t_count ? n_idle : t_count;
         if (got) {
           const uint32_t r = lane_rank(m_idle);
           if (!have_ray && r < got) {
-            my_slot = tlist[t_count - 1u - r];
-            o = mk(SLOT_F(FF_O, my_slot), SLOT_F(FF_O + 1, my_slot), SLOT_F(FF_O + 2, my_slot));
-            d = mk(SLOT_F(FF_D, my_slot), SLOT_F(FF_D + 1, my_slot), SLOT_F(FF_D + 2, my_slot));
-            time = SLOT_F(FF_TIME, my_slot);
-            const uint32_t xy = SLOT_U(FF_XY, my_slot);
-            r_pixel = (load_const(&lc->P.ny) - 1u - (xy >> 16)) * load_const(&lc->P.nx) + (xy & 0xffffu);
-            r_sample = SLOT_U(FF_SAMPLE, my_slot);
-            r_event = SLOT_U(FF_BOUNCES, my_slot) + 1u;
-            inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
-            pc = 0, best = F32_MAX, hmat = NO_HIT;
-            depth = 0, tag = 0, nhits = 0, root_hits = 0, ev_draws = 0;
+            const uint32_t i = t_count - 1u - r;  // pop
+            o = mk(TQ_LD_F(TQ_O, i), TQ_LD_F(TQ_O + 1, i), TQ_LD_F(TQ_O + 2, i));
+            d = mk(TQ_LD_F(TQ_D, i), TQ_LD_F(TQ_D + 1, i), TQ_LD_F(TQ_D + 2, i));
+            time = TQ_LD_F(TQ_TIME, i);
+            r_strength = mk(TQ_LD_F(TQ_STRENGTH, i), TQ_LD_F(TQ_STRENGTH + 1, i), TQ_LD_F(TQ_STRENGTH + 2, i));
+            r_xy = TQ_LD_U(TQ_XY, i), r_sample = TQ_LD_U(TQ_SAMPLE, i), r_bounces = TQ_LD_U(TQ_BOUNCES, i);
+            if (COUNT && tr_out) tr_d = TQ_LD_U(TQ_TRACE, i), tr_a = TQ_LD_U(TQ_TRACE + 1, i), tr_p = TQ_LD_U(TQ_TRACE + 2, i);
+            pc = 0, best = F32_MAX, hmat = NO_HIT, ev_draws = 0;
+            depth = 0, tag = 0, nhits = 0, root_hits = 0;
             bmode = 0, t_lo = t_near;
             if (COUNT) tr_a0 = cnt.aabb, tr_p0 = cnt.prim;
-            cur_lo = RT_FETCH_LO(0), cur_hi = RT_FETCH_HI(0);
             have_ray = true;
           }
           t_count -= got;
           if (COUNT) n_refill++;
         }
       }
+      // 1/d and the current record of EVERY lane are (re)derived here -- the same bits for a lane that kept its ray -- so
+      // that these 11 registers are dead across the passes above, which need the room (idle lanes: a stale but valid pc)
+      inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+      cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc);
+      if (COUNT) t_refill += RT_TICK() - t_mark2;
       if (COUNT) t_serv += RT_TICK() - t_mark;
       if (n_dead == FPOOL) break;
       if (__builtin_amdgcn_ballot_w64(have_ray) == 0) continue;
@@ -398,7 +452,11 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
     // ============================== TRAVERSE ======================================================
     // box runs and slow passes alternate in this inner loop until a service is due (rt_pool.h)
     for (;;) {
+#define RT_R_PIXEL ((load_const(&lc->P.ny) - 1u - (r_xy >> 16)) * load_const(&lc->P.nx) + (r_xy & 0xffffu))
+#define RT_R_EVENT (r_bounces + 1u)
 #include "rt_full_traverse.inc"
+#undef RT_R_PIXEL
+#undef RT_R_EVENT
     op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
     const uint32_t busy = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op >= OP_BOX && op <= OP_SLOW_LAST));
     if (64u - busy >= tune.refill_min || busy == 0) break;
@@ -416,15 +474,27 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
       atomicAdd(&sched[2], (unsigned long long)n_slow_it), atomicAdd(&sched[3], (unsigned long long)n_slow_lanes);
       atomicAdd(&sched[4], (unsigned long long)n_shade), atomicAdd(&sched[5], (unsigned long long)n_shade_lanes);
       atomicAdd(&sched[6], (unsigned long long)n_refill);
+      atomicAdd(&sched[15], t_refill);
+      atomicAdd(&counters[6], t_fin), atomicAdd(&counters[5], n_serv);
       atomicAdd(&counters[16], t_shade), atomicAdd(&counters[17], t_serv - t_shade), atomicAdd(&counters[18], t_box),
           atomicAdd(&counters[19], t_slow);
     }
   }
+}
+
 #undef RT_IN_LDS
 #undef RT_FETCH_LO
 #undef RT_FETCH_HI
-#undef SLOT_U
-#undef SLOT_F
-}
+#undef Q_ROW
+#undef Q_LD
+#undef Q_ST
+#undef TQ_LD_U
+#undef TQ_LD_F
+#undef TQ_ST_U
+#undef TQ_ST_F
+#undef SQ_LD_U
+#undef SQ_LD_F
+#undef SQ_ST_U
+#undef SQ_ST_F
 
 }  // namespace rtg

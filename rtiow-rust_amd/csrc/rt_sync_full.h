@@ -55,6 +55,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   V3 hp = o, hn = o;
   uint32_t hmat = NO_HIT;
   uint32_t depth = 0, tag = 0, nhits = 0, root_hits = 0, ev_draws = 0;
+  V3 sv_o = mk(0.f, 0.f, 0.f), sv_d = sv_o;  // level 0 of the transform stack (rt_full_ops.inc)
   uint32_t r_pixel = 0, r_sample = 0, r_event = 0;
   uint32_t bmode = 0;
   float t_lo = t_near, b_saved = 0.f, b_t1 = 0.f;
@@ -231,7 +232,11 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
     const bool have_ray = st == ST_TRAV;
     uint32_t op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
     for (;;) {
+#define RT_R_PIXEL r_pixel
+#define RT_R_EVENT r_event
 #include "rt_full_traverse.inc"
+#undef RT_R_PIXEL
+#undef RT_R_EVENT
     op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
     if (__builtin_amdgcn_ballot_w64(op >= OP_BOX && op <= OP_SLOW_LAST) == 0) break;
     }

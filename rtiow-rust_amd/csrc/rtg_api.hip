@@ -363,10 +363,10 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
   uint32_t* queue = (uint32_t*)(s->d_counters + 7);
   e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
-  // Program placement: the whole program in LDS when it fits beside the lists, else a leading window
+  // Program placement: the whole program in LDS when it fits, else a leading window
   // (depth-first order: the window holds whole leading subtrees) and global memory for the rest.
   const size_t list_bytes = full_pool_lds_bytes(0, waves);
-  const size_t budget = 158 * 1024;
+  const size_t budget = 160 * 1024;  // all of a CU's LDS: one workgroup per CU
   uint32_t window = s->n_prog;
   int prog = 1;
   if ((size_t)window * 32 + list_bytes > budget) window = (uint32_t)((budget - list_bytes) / 32), prog = 2;
@@ -920,11 +920,17 @@ int rtg_par_cast_device(rtg_scene* s, const rtg_camera* camera, const rtg_params
         fprintf(stderr, "[rtg] wave timeline (us from its start): sees the work queue empty at min %.0f / mean %.0f / max %.0f; done at mean %.0f / max %.0f\n",
                 (double)((1ull << 62) - q[19]) * us, (double)q[20] / n * us, (double)q[21] * us, (double)q[17] / n * us, (double)q[16] * us);
       }
-      double tt = (double)(q[8] + q[9] + q[10] + q[11]);
+      double tt = (double)(q[8] + q[9] + q[10] + q[11]);  // (q[9] = service minus shade)
       fprintf(stderr, "[rtg] wave-time shares (s_memtime, instrumented variant): shade %.1f%% gen+pull|service %.1f%% box %.1f%% sphere %.1f%%; "
               "per pass: shade %.0f, gen|service %.0f, box %.0f, sphere %.0f ticks\n", 100 * q[8] / tt, 100 * q[9] / tt, 100 * q[10] / tt,
               100 * q[11] / tt, q[4] ? (double)q[8] / q[4] : 0., q[4] ? (double)q[9] / q[4] : 0., q[0] ? (double)q[10] / q[0] : 0.,
               q[2] ? (double)q[11] / q[2] : 0.);
+      if (q[15]) {  // full-feature pool kernel: the steps of a service
+        unsigned long long f[2];
+        HIP_TRY(hipMemcpy(f, s->d_counters + 5, sizeof(f), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[rtg] services %llu: finish step %.1f%% of wave time (%.0f ticks each), refill step %.1f%% (%.0f ticks per refill)\n", f[0],
+                100 * f[1] / tt, f[0] ? (double)f[1] / f[0] : 0., 100 * q[15] / tt, q[6] ? (double)q[15] / q[6] : 0.);
+      }
       fprintf(stderr, "[rtg] pool schedule: box steps %llu (avg %.1f lanes), sphere passes %llu (avg %.1f lanes), shade passes %llu "
                 "(avg %.1f lanes), end passes %llu (avg %.1f lanes), refills %llu\n", q[0], q[0] ? (double)q[1] / q[0] : 0.0, q[2],
                 q[2] ? (double)q[3] / q[2] : 0.0, q[4], q[4] ? (double)q[5] / q[4] : 0.0, q[12], q[12] ? (double)q[13] / q[12] : 0.0, q[6]);
