@@ -52,9 +52,23 @@ RT_DEV bool work_to_pixel(const DevParams& P, uint32_t w, uint32_t& x, uint32_t&
   return x < P.nx && row < P.ny;
 }
 
+// A wave-uniform pointer derived from threadIdx (the wave's own memory): readfirstlane tells the compiler it is uniform
+template <typename T>
+RT_DEV T* uniform_ptr(T* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
+}
+
 #define RT_TICK() (COUNT ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull)
 
 
+#ifndef RT_UNIFORM_SLOT_PTR
+#define RT_UNIFORM_SLOT_PTR 1
+#endif
+#ifndef RT_GATED_SERVICE
+#define RT_GATED_SERVICE 1
+#endif
 #ifndef RT_POOL_SLOTS
 #define RT_POOL_SLOTS 144  // 8 global dwords x 144 slots x 4 096 waves = 2.4 MB per XCD: the slot rows stay in the 4 MB L2s
 #endif
@@ -382,7 +396,11 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
 #define RT_SPHERE_MAT(pc_) (USE_LDS ? RT_AS3(uint32_t, (pc_)) : sc.hi[(pc_) >> 4].z)
 #define RT_FETCH_MATLO(i_) (USE_LDS ? lds_u4(pc0 + image + 16u * (i_)) : sc.mat[2u * (i_)])
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, n_waves = blockDim.x >> 6;
+#if RT_UNIFORM_SLOT_PTR
+  uint32_t* slot = uniform_ptr(g_slots + ((size_t)blockIdx.x * n_waves + wave) * (POOL * POOL_FIELDS));
+#else
   uint32_t* slot = g_slots + ((size_t)blockIdx.x * n_waves + wave) * (POOL * POOL_FIELDS);
+#endif
   float* slotf = reinterpret_cast<float*>(slot);
   uint16_t* tlist = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(s_mem) + staged) + wave * (3u * POOL);
   uint16_t* slist = tlist + POOL;
@@ -497,7 +515,15 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
     const uint64_t m_sph = __builtin_amdgcn_ballot_w64(op == OP_SPHERE);
     const uint32_t n_busy = (uint32_t)__builtin_popcountll(m_box | m_sph);
     // ============================== SERVICE ======================================================
-    if (64u - n_busy >= tune.refill_min || n_busy == 0) {
+    // due when enough lanes are idle AND it can do something for them: rays to hand out, or a full pass once the lanes at
+    // END are pushed (rays wait in S and E for company: "idle lanes" alone would call it after every step of a starved wave)
+#if RT_GATED_SERVICE
+    const uint32_t n_fin = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op == OP_END));
+    const bool can_serve = t_count != 0u || s_count + n_fin >= 64u || e_count + n_fin >= 64u;
+#else
+    const bool can_serve = true;
+#endif
+    if ((64u - n_busy >= tune.refill_min && can_serve) || n_busy == 0) {
       if (COUNT) t_mark = RT_TICK();
       // (1) finish: rays that reached END hand (best, best_pc) to their slot and join the E- or S-list
       {

@@ -112,14 +112,6 @@ RT_DEV void full_push_finished(const QueueRsrc qr, uint32_t& s_count, uint32_t& 
   x_count += (uint32_t)__builtin_popcountll(m_x);
 }
 
-// A wave-uniform pointer derived from threadIdx (the wave's own memory): readfirstlane tells the compiler it is uniform
-template <typename T>
-RT_DEV T* uniform_ptr(T* p) {
-  const uint64_t v = reinterpret_cast<uint64_t>(p);
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
-}
-
 // GENB: the scene holds a ConstantMedium whose boundary is an object graph (F_GENERAL_BOUNDARY, e.g. the book's smoke
 // boxes: ConstantMedium<Translate<RotateY<And<...>>>>, object.rs:533-575).  Its two boundary queries
 // (`boundary.hit(f32::MIN..f32::MAX)`, then `boundary.hit(t1 + 0.0001..f32::MAX)`, object.rs:551-552) run THROUGH THE SAME
