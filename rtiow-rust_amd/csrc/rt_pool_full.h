@@ -25,7 +25,8 @@
 namespace rtg {
 
 #ifndef RT_FULL_POOL_SLOTS
-#define RT_FULL_POOL_SLOTS 160  // 128: gather points and slow passes run short of waiting lanes (book-2 +15 %); 192: +2.5 %
+#define RT_FULL_POOL_SLOTS 224  // 64 in the lanes + rays that wait for company in S, X and N (up to 63 each) + T to refill from;
+                                // book-2: 160 52.6 ms (the lanes starve), 192 45.3, 224 43.9, 256 44.6, 320 45.4
 #endif
 constexpr uint32_t FPOOL = RT_FULL_POOL_SLOTS;  // paths in flight per wave of the full-feature kernel = capacity of each stack
 enum FullTField : uint32_t {  // T stack: a ray ready to traverse (the *_TRACE rows only exist for the instrumented variant)
@@ -35,7 +36,9 @@ enum FullSField : uint32_t {  // S / X stacks: a finished ray with its hit recor
   SQ_P = 0, SQ_N = 3, SQ_D = 6, SQ_TIME = 9, SQ_HITMAT = 10, SQ_EVDRAWS = 11, SQ_STRENGTH = 12, SQ_BOUNCES = 15, SQ_SAMPLE = 16,
   SQ_XY = 17, SQ_TRACE = 18, SQ_FIELDS = 21,
 };
-constexpr uint32_t FPOOL_FIELDS = TQ_FIELDS + 2 * SQ_FIELDS;  // dwords of stack space per path in flight (T, S, X)
+enum FullNField : uint32_t { NQ_SAMPLE = 0, NQ_XY = 1, NQ_FIELDS = 2 };  // N stack: a path that ended asks for its successor
+constexpr uint32_t NQ_NEED_ITEM = 0xffffffffu;  // NQ_SAMPLE: "the next work item" instead of "sample s of the same pixel"
+constexpr uint32_t FPOOL_FIELDS = TQ_FIELDS + 2 * SQ_FIELDS + NQ_FIELDS;  // dwords of stack space per path in flight (T, S, X, N)
 
 // LDS = the first `window` program records (all of them when the program fits, 0 = none)
 inline size_t full_pool_lds_bytes(uint32_t window, uint32_t /*waves*/) { return (size_t)window * 32; }
@@ -62,7 +65,7 @@ __device__ __attribute__((noinline)) float event_draw_f32(uint64_t seed, uint32_
 // ---- stack access: `qr` = the wave's stack space
 RT_DEV uint32_t f2u(float f) { return __float_as_uint(f); }
 typedef __amdgpu_buffer_rsrc_t QueueRsrc;
-constexpr uint32_t SQ_BASE = TQ_FIELDS;  // first row of the S (+X) stacks
+constexpr uint32_t SQ_BASE = TQ_FIELDS, NQ_BASE = TQ_FIELDS + 2u * SQ_FIELDS;  // first rows of the S (+X) and N stacks
 RT_DEV QueueRsrc make_queue_rsrc(uint32_t* wave_base) {
   // raw buffer (stride 0, bounds = the wave's stack space in bytes; word 3 = gfx9 raw-buffer format bits)
   return __builtin_amdgcn_make_buffer_rsrc(wave_base, 0, FPOOL * FPOOL_FIELDS * 4u, 0x00020000);
@@ -83,6 +86,8 @@ RT_DEV QueueRsrc make_queue_rsrc(uint32_t* wave_base) {
 #define SQ_LD_F(f_, i_) u2f(SQ_LD_U(f_, i_))
 #define SQ_ST_U(f_, i_, v_) Q_ST(Q_ROW(SQ_BASE, f_), i_, (uint32_t)(v_))
 #define SQ_ST_F(f_, i_, v_) Q_ST(Q_ROW(SQ_BASE, f_), i_, f2u(v_))
+#define NQ_LD_U(f_, i_) Q_LD(Q_ROW(NQ_BASE, f_), i_)
+#define NQ_ST_U(f_, i_, v_) Q_ST(Q_ROW(NQ_BASE, f_), i_, (uint32_t)(v_))
 constexpr uint32_t XQ = SQ_FIELDS * FPOOL;  // X stack = positions XQ.. of the S rows: hits on checker / Perlin materials
 
 // Push finished rays onto S or X: consecutive positions (wave-uniform call; `fin` selects the lanes).
@@ -152,11 +157,11 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   uint32_t* tq = uniform_ptr(g_slots + gwave * (FPOOL * FPOOL_FIELDS));
   const QueueRsrc qr = make_queue_rsrc(tq);                  // rows: T, then S (+X), then G (+R) -- see Q_ROW
   float* stack = uniform_ptr(g_stack + gwave * (STACK_LEVELS * 6 * 64));  // [level][component][lane]; level 0 rides in registers
-  for (uint32_t j = lane; j < FPOOL; j += 64u) SQ_ST_U(SQ_HITMAT, j, SLOT_NEED_PIXEL);  // FPOOL entries that ask for a work item
+  for (uint32_t j = lane; j < FPOOL; j += 64u) NQ_ST_U(NQ_SAMPLE, j, NQ_NEED_ITEM);  // FPOOL paths-to-be ask for a work item
   __syncthreads();
 
   const float t_near = load_const(&lc->P.t_near);
-  uint32_t t_count = 0, s_count = FPOOL, x_count = 0, n_dead = 0;
+  uint32_t t_count = 0, s_count = 0, x_count = 0, n_count = FPOOL, n_dead = 0;
   uint32_t w_next = 0, w_end = 0, w_chunk = 0, w_delta = 0;
   bool w_lpt_ready = false;
   bool exhausted = false;
@@ -181,6 +186,8 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   uint32_t tr_a0 = 0, tr_p0 = 0, tr_d = 0, tr_a = 0, tr_p = 0;  // the path's running draws / Aabb tests / primitive tests
   if (COUNT) tr_out = reinterpret_cast<uint32_t*>(counters[30]);
   uint32_t n_box_it = 0, n_box_lanes = 0, n_slow_it = 0, n_slow_lanes = 0, n_shade = 0, n_shade_lanes = 0, n_refill = 0;
+  uint32_t n_gen = 0, n_gen_lanes = 0;
+  unsigned long long t_gen = 0;
   unsigned long long t_shade = 0, t_serv = 0, t_box = 0, t_slow = 0, t_refill = 0, t_fin = 0, n_serv = 0, t_mark = 0, t_mark2 = 0;  // COUNT: s_memtime shares
 
 #include "rt_full_ops.inc"
@@ -206,7 +213,8 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       if (COUNT) t_fin += RT_TICK() - t_mark, n_serv++;
-      // (2) shade
+      // (2) shade: Material::scatter for 64 finished rays (color() loop body, lib.rs:73-97).  A path that goes on is pushed onto
+      // T; one that ends books its sample colour and asks for its successor on N (the next sample of its work item, or a new item)
       auto shade_pass = [&](auto textured_tag, const uint32_t q0, uint32_t& count) {  // q0 = 0 (S) or XQ (X)
         constexpr bool TEXTURED = decltype(textured_tag)::value;
         constexpr uint32_t PASS_FEAT = TEXTURED ? FEAT : (FEAT & ~FEAT_TEXTURE);
@@ -216,7 +224,6 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         const uint32_t take = count < 64u ? count : 64u;
         count -= take;
         if (COUNT) n_shade++, n_shade_lanes += take, t_mark2 = RT_TICK();
-        uint32_t st = ST_DEAD;
         uint32_t trd = 0, tra = 0, trp = 0;
         V3 so = mk(0.f, 0.f, 0.f), sd = so, strength = so;
         // no accum field: it is +0 whenever it is read (rt_pool.h PoolField; the host only routes scenes
@@ -224,116 +231,148 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         V3 accum = so;
         float stime = 0.f;
         uint32_t bounces = 0, s = 0, x = 0, row = 0;
-        bool lpt_on = false;
+        bool lpt_on = false, live = false, ended = false;
         if (lane < take) {
           const uint32_t j = q0 + count + lane;  // pop: the top `take` entries
           const uint32_t hm = SQ_LD_U(SQ_HITMAT, j);
-          if (hm == SLOT_NEED_PIXEL) {
-            st = ST_NEED_PIXEL;
-          } else {
-            // The texture value is fetched FIRST, while almost nothing of this pass is live: texture_eval
-            // (Perlin turbulence / checker) is an out-of-line call and everything live across it adds to
-            // the kernel's register count.
-            const V3 p = mk(SQ_LD_F(SQ_P, j), SQ_LD_F(SQ_P + 1, j), SQ_LD_F(SQ_P + 2, j));
-            uint4 mlo = make_uint4(0, 0, 0, 0), mhi = make_uint4(0, 0, 0, 0);
-            V3 texval = mk(0.f, 0.f, 0.f);
-            if (hm != NO_HIT) {
-              mlo = sc.mat[2 * hm], mhi = sc.mat[2 * hm + 1];
-              texval = material_texture<PASS_FEAT>(sc, mlo, mhi, p);  // = albedo / emission colour for constant textures
-            }
-            sd = mk(SQ_LD_F(SQ_D, j), SQ_LD_F(SQ_D + 1, j), SQ_LD_F(SQ_D + 2, j));
-            stime = SQ_LD_F(SQ_TIME, j);
-            strength = mk(SQ_LD_F(SQ_STRENGTH, j), SQ_LD_F(SQ_STRENGTH + 1, j), SQ_LD_F(SQ_STRENGTH + 2, j));
-            bounces = SQ_LD_U(SQ_BOUNCES, j), s = SQ_LD_U(SQ_SAMPLE, j);
-            if (COUNT && tr_out) trd = SQ_LD_U(SQ_TRACE, j), tra = SQ_LD_U(SQ_TRACE + 1, j), trp = SQ_LD_U(SQ_TRACE + 2, j);
-            const uint32_t xy = SQ_LD_U(SQ_XY, j);
-            x = xy & 0xffffu, row = xy >> 16;
-            // ---------------- color() loop body, lib.rs:73-97 ----------------
-            SampleRng rng;
-            rng.init(seed, (P.ny - 1u - row) * P.nx + x, s);
-            rng.set_event(bounces + 1u);
-            rng.seek(SQ_LD_U(SQ_EVDRAWS, j));  // continue after the medium draws of this event's traversal
-            bool ended = true;
-            V3 result = mk(0.f, 0.f, 0.f);
-            if (hm != NO_HIT) {
-              if (COUNT) cnt.shaded++;
-              const V3 n = mk(SQ_LD_F(SQ_N, j), SQ_LD_F(SQ_N + 1, j), SQ_LD_F(SQ_N + 2, j));
-              const uint32_t kind = mhi.w & 0xffu;
-              const float param = u2f(mlo.w);
-              V3 emitted = mk(0.f, 0.f, 0.f);
-              if (kind == MAT_DIFFUSE_LIGHT) emitted = smul(param, texval);  // material.rs:120-128
-              accum = vadd(accum, vmul(strength, emitted));
-              V3 nd = mk(0.f, 0.f, 0.f), att = texval;  // Lambertian / Isotropic: albedo(p)
-              bool scattered = true;
-              V3 rs = mk(0.f, 0.f, 0.f);
-              if (kind == MAT_LAMBERTIAN || kind == MAT_METAL || kind == MAT_ISOTROPIC) rs = in_unit_sphere(rng);
-              float sd_len = 0.f;  // |d| and unit(d) once for the Metal and the Dielectric lanes (rt_pool.h)
-              V3 sd_unit = sd;
-              if (kind == MAT_METAL || kind == MAT_DIELECTRIC) sd_len = vlen(sd), sd_unit = sdiv(sd, sd_len);
-              if (kind == MAT_LAMBERTIAN) {
-                V3 target = vadd(vadd(p, n), rs);
-                nd = vsub(target, p);
-              } else if (kind == MAT_METAL) {
-                V3 refl = reflect(sd_unit, n);
-                nd = vadd(refl, smul(param, rs));
-                att = mk(u2f(mlo.x), u2f(mlo.y), u2f(mlo.z));
-                scattered = vdot(nd, n) > 0.f;
-              } else if (kind == MAT_DIELECTRIC) {
-                V3 outward;
-                float ni_over_nt, cosine;
-                float dn = vdot(sd, n);
-                if (dn > 0.f) {
-                  outward = vneg(n);
-                  ni_over_nt = param;
-                  cosine = param * dn / sd_len;
-                } else {
-                  outward = n;
-                  ni_over_nt = 1.0f / param;
-                  cosine = -dn / sd_len;
-                }
-                V3 uv = sd_unit;
-                float dt = vdot(uv, outward);
-                float disc = 1.0f - ni_over_nt * ni_over_nt * (1.f - dt * dt);
-                bool refracted = disc > 0.f;
-                if (refracted) {
-                  nd = vsub(smul(ni_over_nt, vsub(uv, smul(dt, outward))), smul(__builtin_sqrtf(disc), outward));
-                  refracted = rng.gen_f32() >= schlick(cosine, param);
-                }
-                if (!refracted) nd = reflect(sd, n);
-                att = splat(1.f);
-              } else if (kind == MAT_DIFFUSE_LIGHT) {
-                scattered = false;
-              } else {  // Isotropic
-                nd = rs;
+          // The texture value is fetched FIRST, while almost nothing of this pass is live: texture_eval
+          // (Perlin turbulence / checker) is an out-of-line call and everything live across it adds to
+          // the kernel's register count.
+          const V3 p = mk(SQ_LD_F(SQ_P, j), SQ_LD_F(SQ_P + 1, j), SQ_LD_F(SQ_P + 2, j));
+          uint4 mlo = make_uint4(0, 0, 0, 0), mhi = make_uint4(0, 0, 0, 0);
+          V3 texval = mk(0.f, 0.f, 0.f);
+          if (hm != NO_HIT) {
+            mlo = sc.mat[2 * hm], mhi = sc.mat[2 * hm + 1];
+            texval = material_texture<PASS_FEAT>(sc, mlo, mhi, p);  // = albedo / emission colour for constant textures
+          }
+          sd = mk(SQ_LD_F(SQ_D, j), SQ_LD_F(SQ_D + 1, j), SQ_LD_F(SQ_D + 2, j));
+          stime = SQ_LD_F(SQ_TIME, j);
+          strength = mk(SQ_LD_F(SQ_STRENGTH, j), SQ_LD_F(SQ_STRENGTH + 1, j), SQ_LD_F(SQ_STRENGTH + 2, j));
+          bounces = SQ_LD_U(SQ_BOUNCES, j), s = SQ_LD_U(SQ_SAMPLE, j);
+          if (COUNT && tr_out) trd = SQ_LD_U(SQ_TRACE, j), tra = SQ_LD_U(SQ_TRACE + 1, j), trp = SQ_LD_U(SQ_TRACE + 2, j);
+          const uint32_t xy = SQ_LD_U(SQ_XY, j);
+          x = xy & 0xffffu, row = xy >> 16;
+          SampleRng rng;
+          rng.init(seed, (P.ny - 1u - row) * P.nx + x, s);
+          rng.set_event(bounces + 1u);
+          rng.seek(SQ_LD_U(SQ_EVDRAWS, j));  // continue after the medium draws of this event's traversal
+          ended = true;
+          V3 result = mk(0.f, 0.f, 0.f);
+          if (hm != NO_HIT) {
+            if (COUNT) cnt.shaded++;
+            const V3 n = mk(SQ_LD_F(SQ_N, j), SQ_LD_F(SQ_N + 1, j), SQ_LD_F(SQ_N + 2, j));
+            const uint32_t kind = mhi.w & 0xffu;
+            const float param = u2f(mlo.w);
+            V3 emitted = mk(0.f, 0.f, 0.f);
+            if (kind == MAT_DIFFUSE_LIGHT) emitted = smul(param, texval);  // material.rs:120-128
+            accum = vadd(accum, vmul(strength, emitted));
+            V3 nd = mk(0.f, 0.f, 0.f), att = texval;  // Lambertian / Isotropic: albedo(p)
+            bool scattered = true;
+            V3 rs = mk(0.f, 0.f, 0.f);
+            if (kind == MAT_LAMBERTIAN || kind == MAT_METAL || kind == MAT_ISOTROPIC) rs = in_unit_sphere(rng);
+            float sd_len = 0.f;  // |d| and unit(d) once for the Metal and the Dielectric lanes (rt_pool.h)
+            V3 sd_unit = sd;
+            if (kind == MAT_METAL || kind == MAT_DIELECTRIC) sd_len = vlen(sd), sd_unit = sdiv(sd, sd_len);
+            if (kind == MAT_LAMBERTIAN) {
+              V3 target = vadd(vadd(p, n), rs);
+              nd = vsub(target, p);
+            } else if (kind == MAT_METAL) {
+              V3 refl = reflect(sd_unit, n);
+              nd = vadd(refl, smul(param, rs));
+              att = mk(u2f(mlo.x), u2f(mlo.y), u2f(mlo.z));
+              scattered = vdot(nd, n) > 0.f;
+            } else if (kind == MAT_DIELECTRIC) {
+              V3 outward;
+              float ni_over_nt, cosine;
+              float dn = vdot(sd, n);
+              if (dn > 0.f) {
+                outward = vneg(n);
+                ni_over_nt = param;
+                cosine = param * dn / sd_len;
+              } else {
+                outward = n;
+                ni_over_nt = 1.0f / param;
+                cosine = -dn / sd_len;
               }
-              result = accum;
-              if (scattered) {
-                so = p, sd = nd;  // time is carried over by every material
-                strength = vmul(strength, att);
-                if (bounces != P.max_bounces) {
-                  bounces += 1;
-                  ended = false;
-                  lpt_on = s < cm.lpt_samples && bounces == cm.lpt_deep;  // phase 1 of the cost-ordered queue (rt_pool.h)
-                }
+              V3 uv = sd_unit;
+              float dt = vdot(uv, outward);
+              float disc = 1.0f - ni_over_nt * ni_over_nt * (1.f - dt * dt);
+              bool refracted = disc > 0.f;
+              if (refracted) {
+                nd = vsub(smul(ni_over_nt, vsub(uv, smul(dt, outward))), smul(__builtin_sqrtf(disc), outward));
+                refracted = rng.gen_f32() >= schlick(cosine, param);
+              }
+              if (!refracted) nd = reflect(sd, n);
+              att = splat(1.f);
+            } else if (kind == MAT_DIFFUSE_LIGHT) {
+              scattered = false;
+            } else {  // Isotropic
+              nd = rs;
+            }
+            result = accum;
+            if (scattered) {
+              so = p, sd = nd;  // time is carried over by every material
+              strength = vmul(strength, att);
+              if (bounces != P.max_bounces) {
+                bounces += 1;
+                ended = false;
+                lpt_on = s < cm.lpt_samples && bounces == cm.lpt_deep;  // phase 1 of the cost-ordered queue (rt_pool.h)
               }
             }
-            if (COUNT) total_draws += rng.draws;
-            if (COUNT) trd += rng.draws;
-            if (ended) {
-              float* sp = cm.scratch + 3ull * ((size_t)s * cm.pix_work + pixel_to_work(P, x, row));
-              RT_SCRATCH_STORE(sp, result);
-              if (COUNT && tr_out) {
-                uint32_t* tp = tr_out + 4ull * ((size_t)s * cm.pix_work + pixel_to_work(P, x, row));
-                tp[0] = bounces, tp[1] = trd, tp[2] = tra, tp[3] = trp;
-              }
-              s++;
-              st = (s == P.ns || s % cm.chunk == 0u) ? ST_NEED_PIXEL : ST_GEN;
-            } else {
-              st = ST_TRAV;
+          }
+          if (COUNT) total_draws += rng.draws;
+          if (COUNT) trd += rng.draws;
+          live = !ended;
+          if (ended) {
+            float* sp = cm.scratch + 3ull * ((size_t)s * cm.pix_work + pixel_to_work(P, x, row));
+            RT_SCRATCH_STORE(sp, result);
+            if (COUNT && tr_out) {
+              uint32_t* tp = tr_out + 4ull * ((size_t)s * cm.pix_work + pixel_to_work(P, x, row));
+              tp[0] = bounces, tp[1] = trd, tp[2] = tra, tp[3] = trp;
             }
+            s++;
           }
         }
         if (cm.lpt_samples) lpt_count(cm, lpt_on, lpt_on ? pixel_to_work(P, x, row) >> 8 : 0u);
+        const uint64_t m_live = __builtin_amdgcn_ballot_w64(live), m_end = __builtin_amdgcn_ballot_w64(ended);
+        if (live) {  // push onto T
+          const uint32_t i = t_count + lane_rank(m_live);
+          TQ_ST_F(TQ_O, i, so.x), TQ_ST_F(TQ_O + 1, i, so.y), TQ_ST_F(TQ_O + 2, i, so.z);
+          TQ_ST_F(TQ_D, i, sd.x), TQ_ST_F(TQ_D + 1, i, sd.y), TQ_ST_F(TQ_D + 2, i, sd.z);
+          TQ_ST_F(TQ_TIME, i, stime);
+          TQ_ST_F(TQ_STRENGTH, i, strength.x), TQ_ST_F(TQ_STRENGTH + 1, i, strength.y), TQ_ST_F(TQ_STRENGTH + 2, i, strength.z);
+          TQ_ST_U(TQ_BOUNCES, i, bounces), TQ_ST_U(TQ_SAMPLE, i, s);
+          TQ_ST_U(TQ_XY, i, x | (row << 16));
+          if (COUNT && tr_out) TQ_ST_U(TQ_TRACE, i, trd), TQ_ST_U(TQ_TRACE + 1, i, tra), TQ_ST_U(TQ_TRACE + 2, i, trp);
+          if (COUNT) cnt.rays++;
+        }
+        if (ended) {  // push onto N: the next sample of this work item, or "a new item, please"
+          const uint32_t i = n_count + lane_rank(m_end);
+          NQ_ST_U(NQ_SAMPLE, i, (s == P.ns || s % cm.chunk == 0u) ? NQ_NEED_ITEM : s);
+          NQ_ST_U(NQ_XY, i, x | (row << 16));
+        }
+        t_count += (uint32_t)__builtin_popcountll(m_live);
+        n_count += (uint32_t)__builtin_popcountll(m_end);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (COUNT) t_shade += RT_TICK() - t_mark2;
+      };
+      // (2b) camera rays for 64 paths that begin (par_cast closure, lib.rs:366-371: event 0): the next sample of the work item,
+      // or the next work item of this wave's reservation (rt_pool.h)
+      auto gen_pass = [&]() {
+        const DevParams P = load_const(&lc->P);
+        const ChunkMode cm = load_const(&lc->cm);
+        const uint64_t seed = ((uint64_t)P.seed_hi << 32) | P.seed_lo;
+        const uint32_t take = n_count < 64u ? n_count : 64u;
+        n_count -= take;
+        if (COUNT) n_gen++, n_gen_lanes += take, t_mark2 = RT_TICK();
+        uint32_t st = ST_DEAD, s = 0, x = 0, row = 0;
+        if (lane < take) {
+          const uint32_t j = n_count + lane;
+          s = NQ_LD_U(NQ_SAMPLE, j);
+          const uint32_t xy = NQ_LD_U(NQ_XY, j);
+          x = xy & 0xffffu, row = xy >> 16;
+          st = s == NQ_NEED_ITEM ? ST_NEED_PIXEL : ST_GEN;
+        }
         for (;;) {  // next work item (see rt_pool.h)
           const uint64_t need = __builtin_amdgcn_ballot_w64(st == ST_NEED_PIXEL);
           if (need == 0) break;
@@ -367,43 +406,41 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           const uint32_t n_need = (uint32_t)__builtin_popcountll(need);
           w_next += n_need < avail ? n_need : avail;
         }
-        if (st == ST_GEN) {  // par_cast closure, lib.rs:366-371 (event 0)
+        const bool live = st == ST_GEN;
+        const uint64_t m_live = __builtin_amdgcn_ballot_w64(live);
+        if (live) {
           const uint32_t y = P.ny - 1u - row;
           SampleRng rng;
           rng.init(seed, y * P.nx + x, s);
           float u = ((float)x + rng.gen_f32()) / (float)P.nx;
           float v = ((float)y + rng.gen_f32()) / (float)P.ny;
           const DevCamera cam = load_const(&lc->cam);
+          V3 so, sd;
+          float stime;
           get_ray(cam, u, v, rng, so, sd, stime);
-          accum = mk(0.f, 0.f, 0.f), strength = splat(1.f), bounces = 0;
           if (COUNT) total_draws += rng.draws;
-          if (COUNT) trd = rng.draws, tra = 0u, trp = 0u;
-          st = ST_TRAV;
-        }
-        const bool live = st == ST_TRAV;
-        const uint64_t m_live = __builtin_amdgcn_ballot_w64(live);
-        if (live) {  // push onto T
           const uint32_t i = t_count + lane_rank(m_live);
           TQ_ST_F(TQ_O, i, so.x), TQ_ST_F(TQ_O + 1, i, so.y), TQ_ST_F(TQ_O + 2, i, so.z);
           TQ_ST_F(TQ_D, i, sd.x), TQ_ST_F(TQ_D + 1, i, sd.y), TQ_ST_F(TQ_D + 2, i, sd.z);
           TQ_ST_F(TQ_TIME, i, stime);
-          TQ_ST_F(TQ_STRENGTH, i, strength.x), TQ_ST_F(TQ_STRENGTH + 1, i, strength.y), TQ_ST_F(TQ_STRENGTH + 2, i, strength.z);
-          TQ_ST_U(TQ_BOUNCES, i, bounces), TQ_ST_U(TQ_SAMPLE, i, s);
+          TQ_ST_F(TQ_STRENGTH, i, 1.f), TQ_ST_F(TQ_STRENGTH + 1, i, 1.f), TQ_ST_F(TQ_STRENGTH + 2, i, 1.f);
+          TQ_ST_U(TQ_BOUNCES, i, 0u), TQ_ST_U(TQ_SAMPLE, i, s);
           TQ_ST_U(TQ_XY, i, x | (row << 16));
-          if (COUNT && tr_out) TQ_ST_U(TQ_TRACE, i, trd), TQ_ST_U(TQ_TRACE + 1, i, tra), TQ_ST_U(TQ_TRACE + 2, i, trp);
+          if (COUNT && tr_out) TQ_ST_U(TQ_TRACE, i, rng.draws), TQ_ST_U(TQ_TRACE + 1, i, 0u), TQ_ST_U(TQ_TRACE + 2, i, 0u);
           if (COUNT) cnt.rays++;
         }
         t_count += (uint32_t)__builtin_popcountll(m_live);
         n_dead += take - (uint32_t)__builtin_popcountll(m_live);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        if (COUNT) t_shade += RT_TICK() - t_mark2;
+        if (COUNT) t_gen += RT_TICK() - t_mark2;
       };
       for (;;) {  // full passes first; partial ones only when the lanes would have nothing to traverse (ONE call site per pass kind)
         const bool any_part = n_busy == 0 && t_count == 0;
-        uint32_t which = s_count >= 64u ? 1u : (TEX && x_count >= 64u) ? 2u : 0u;
-        if (which == 0u && any_part) which = s_count ? 1u : (TEX && x_count) ? 2u : 0u;
+        uint32_t which = s_count >= 64u ? 1u : (TEX && x_count >= 64u) ? 2u : n_count >= 64u ? 3u : 0u;
+        if (which == 0u && any_part) which = n_count ? 3u : s_count ? 1u : (TEX && x_count) ? 2u : 0u;
         if (which == 0u) break;
         if (which == 1u) shade_pass(std::false_type{}, 0u, s_count);
+        else if (which == 3u) gen_pass();
         else if (TEX) shade_pass(std::true_type{}, XQ, x_count);
       }
       if (COUNT) t_mark2 = RT_TICK();
@@ -467,6 +504,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
       atomicAdd(&sched[4], (unsigned long long)n_shade), atomicAdd(&sched[5], (unsigned long long)n_shade_lanes);
       atomicAdd(&sched[6], (unsigned long long)n_refill);
       atomicAdd(&sched[15], t_refill);
+      atomicAdd(&sched[12], (unsigned long long)n_gen), atomicAdd(&sched[13], (unsigned long long)n_gen_lanes), atomicAdd(&sched[14], t_gen);
       atomicAdd(&counters[6], t_fin), atomicAdd(&counters[5], n_serv);
       atomicAdd(&counters[16], t_shade), atomicAdd(&counters[17], t_serv - t_shade), atomicAdd(&counters[18], t_box),
           atomicAdd(&counters[19], t_slow);
@@ -488,5 +526,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
 #undef SQ_LD_F
 #undef SQ_ST_U
 #undef SQ_ST_F
+#undef NQ_LD_U
+#undef NQ_ST_U
 
 }  // namespace rtg

@@ -932,7 +932,7 @@ int rtg_par_cast_device(rtg_scene* s, const rtg_camera* camera, const rtg_params
                 100 * f[1] / tt, f[0] ? (double)f[1] / f[0] : 0., 100 * q[15] / tt, q[6] ? (double)q[15] / q[6] : 0.);
       }
       fprintf(stderr, "[rtg] pool schedule: box steps %llu (avg %.1f lanes), sphere passes %llu (avg %.1f lanes), shade passes %llu "
-                "(avg %.1f lanes), end passes %llu (avg %.1f lanes), refills %llu\n", q[0], q[0] ? (double)q[1] / q[0] : 0.0, q[2],
+                "(avg %.1f lanes), end / camera-ray passes %llu (avg %.1f lanes), refills %llu\n", q[0], q[0] ? (double)q[1] / q[0] : 0.0, q[2],
                 q[2] ? (double)q[3] / q[2] : 0.0, q[4], q[4] ? (double)q[5] / q[4] : 0.0, q[12], q[12] ? (double)q[13] / q[12] : 0.0, q[6]);
     }
   }

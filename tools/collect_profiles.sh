@@ -13,12 +13,13 @@ python bench.py --bvh sah --no-cpu-baseline > $O/bench_sah.json 2>/dev/null
 python bench.py --workload cornell > $O/bench_cornell_c1.json 2>/dev/null
 python bench.py --workload book2 --steps 3 > $O/bench_book2_c4.json 2>/dev/null
 RTG_VERBOSE=1 python tools/time_scenes.py book1 1200 800 50 2>&1 | grep "^\[rtg\] wave\|^\[rtg\] pool sched" | sort -u > $O/schedule_book1.txt
-RTG_VERBOSE=1 python tools/time_scenes.py book2 800 800 100 2>&1 | grep "^\[rtg\] wave\|^\[rtg\] pool sched" | sort -u > $O/schedule_book2.txt
+RTG_VERBOSE=1 python tools/time_scenes.py book2 800 800 100 2>&1 | grep "^\[rtg\] wave\|^\[rtg\] pool sched\|^\[rtg\] services" | sort -u > $O/schedule_book2.txt
 python tools/time_scenes.py cornell 300 300 100 cornell_smoke 300 300 100 book2 800 800 100 book2_bvh 800 800 100 volume 300 300 100 simple_light 300 300 20 simple_light_1000 300 300 20 book1 1200 800 50 2>&1 | grep -v "^\[rtg\]" > $O/time_scenes.txt
 python tools/verify_full.py > $O/verify_full.txt 2>&1
 python tools/tail_probe.py > $O/tail_probe.txt 2>&1
 python tools/criterion_scene.py > $O/criterion_scene.txt 2>&1
 tools/ubench/issue_rate > $O/issue_rate.txt 2>&1
+tools/ubench/mem_latency > $O/mem_latency.txt 2>&1
 python tools/libm_exhaustive_gpu.py > $O/libm_exhaustive_gpu.txt 2>&1
 python -m pytest tests -m gpu -q --timeout=120 > $O/pytest_gpu.log 2>&1
 ls -la $O
