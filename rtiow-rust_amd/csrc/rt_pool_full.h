@@ -190,7 +190,9 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   unsigned long long t_gen = 0;
   unsigned long long t_shade = 0, t_serv = 0, t_box = 0, t_slow = 0, t_refill = 0, t_fin = 0, n_serv = 0, t_mark = 0, t_mark2 = 0;  // COUNT: s_memtime shares
 
+#define RT_REG_STACK0 1  // PUSH / POP of an outermost wrapper touch no memory (book-2: the moving sphere, the sphere cloud)
 #include "rt_full_ops.inc"
+#undef RT_REG_STACK0
 
   for (;;) {
     uint32_t op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;

@@ -67,7 +67,9 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   uint32_t n_box_it = 0, n_box_lanes = 0, n_slow_it = 0, n_slow_lanes = 0, n_shade = 0, n_shade_lanes = 0, n_refill = 0;
   unsigned long long t_shade = 0, t_box = 0, t_slow = 0, t_mark = 0;
 
+#define RT_REG_STACK0 0  // measured: six more live registers cost this kernel 7 % on sphere lists, Cornell's wrappers gain nothing
 #include "rt_full_ops.inc"
+#undef RT_REG_STACK0
 
   for (;;) {
     // ============================== SHADE / GEN (every lane, its own path) ==========================

@@ -189,7 +189,8 @@ struct rtg_scene {
   // 3 = ray-pool kernels (rt_pool.h / rt_pool_full.h), 1 = one-lane-per-pixel baseline (rt_trace.h) for every scene
   int kernel_version = 3;
   PoolTuning pool_tune{40, 16, 24, 16, 16, 40};  // lean ray-pool kernel (refill_min, sphere_min, box_leave: profiles/r02_e_final/lean_knob_sweep.txt)
-  PoolTuning full_tune{20, 16, 32, 16, 16, 40};  // full-feature kernel (a service there also has hit records to move)
+  PoolTuning full_tune{20, 24, 32, 16, 24, 40};  // full-feature pool kernel (a service there also has hit records to move)
+  PoolTuning sync_tune{20, 16, 32, 16, 16, 40};  // lock-step kernel (only run_ahead / run_ahead_min / gather_min matter there)
   int wg_per_cu = 0;                       // 0 = ask the occupancy API
   int full_threads = 0;                    // full-feature pool kernel: 0 = the variant's maximum (RTG_BLOCK overrides)
   int pool_threads = 1024;                 // lean ray-pool kernel: ONE 16-wave workgroup per CU shares one LDS copy of the program
@@ -413,7 +414,7 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
     e = hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k2, dim3(grid), dim3(bt), lds2, stream, s->dev, (const LaunchConsts*)s->d_consts, d_out, (uint32_t)total_work, queue,
-                       s->d_counters, s->full_tune, s->d_stack, window);
+                       s->d_counters, s->sync_tune, s->d_stack, window);
   } else
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(bt), lds, stream, s->dev, (const LaunchConsts*)s->d_consts, d_out, (uint32_t)total_work, queue,
                      s->d_counters, s->full_tune, s->d_slots, s->d_stack, window);
@@ -808,12 +809,12 @@ int rtg_scene_set_option(rtg_scene* s, const char* name, int value) {
   else if (k == "wg_per_cu") s->wg_per_cu = value;
   else if (k == "verbose") s->verbose = value;                  // print launch geometry / schedule statistics to stderr
   else if (k == "window") s->window = value;                    // full-feature kernel: records staged in LDS, -1 = automatic
-  else if (k == "box_leave") s->pool_tune.box_leave = s->full_tune.box_leave = u;
-  else if (k == "refill_min") s->pool_tune.refill_min = s->full_tune.refill_min = u;
-  else if (k == "gather_min") s->pool_tune.gather_min = s->full_tune.gather_min = u;
-  else if (k == "run_ahead") s->pool_tune.run_ahead = s->full_tune.run_ahead = u;
-  else if (k == "run_ahead_min") s->pool_tune.run_ahead_min = s->full_tune.run_ahead_min = u;
-  else if (k == "sphere_min") s->pool_tune.sphere_min = s->full_tune.sphere_min = u;
+  else if (k == "box_leave") s->pool_tune.box_leave = s->full_tune.box_leave = s->sync_tune.box_leave = u;
+  else if (k == "refill_min") s->pool_tune.refill_min = s->full_tune.refill_min = s->sync_tune.refill_min = u;
+  else if (k == "gather_min") s->pool_tune.gather_min = s->full_tune.gather_min = s->sync_tune.gather_min = u;
+  else if (k == "run_ahead") s->pool_tune.run_ahead = s->full_tune.run_ahead = s->sync_tune.run_ahead = u;
+  else if (k == "run_ahead_min") s->pool_tune.run_ahead_min = s->full_tune.run_ahead_min = s->sync_tune.run_ahead_min = u;
+  else if (k == "sphere_min") s->pool_tune.sphere_min = s->full_tune.sphere_min = s->sync_tune.sphere_min = u;
   else return fail(RTG_ERR_INVALID, "rtg_scene_set_option: unknown option '" + k + "'");
   return RTG_OK;
 }

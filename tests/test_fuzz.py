@@ -63,6 +63,8 @@ def test_fuzz_graphs_bit_exact(pkg, gpu, oracle, seed):
     assert_bit_equal(img_g, img_o, "fuzz scene %d" % seed)
     for k in ("aabb_tests", "prim_tests", "shaded_hits", "rays", "draws"):
         assert st_g[k] == st_o[k], (seed, k, st_g[k], st_o[k])
+    # ... and the timed instantiation of the same kernel (no counters: other register allocation, other spills)
+    assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns), img_o, "fuzz scene %d, production variant" % seed)
 
 
 @pytest.mark.gpu
@@ -78,3 +80,4 @@ def test_fuzz_graph_boundaries_bit_exact(pkg, gpu, oracle, seed):
     assert_bit_equal(img_g, img_o, "boundary fuzz scene %d" % seed)
     for k in ("aabb_tests", "prim_tests", "shaded_hits", "rays", "draws"):
         assert st_g[k] == st_o[k], (seed, k, st_g[k], st_o[k])
+    assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns), img_o, "boundary fuzz scene %d, production variant" % seed)
