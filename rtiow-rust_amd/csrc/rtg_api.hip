@@ -188,7 +188,7 @@ struct rtg_scene {
   int lpt_phase1 = 0;          // RTG_LPT_PHASE1: chunks in natural order, 0 = n_chunks / 8 clamped to [2, 8]
   // 3 = ray-pool kernels (rt_pool.h / rt_pool_full.h), 1 = one-lane-per-pixel baseline (rt_trace.h) for every scene
   int kernel_version = 3;
-  PoolTuning pool_tune{40, 16, 24, 16, 16, 40};  // lean ray-pool kernel (refill_min, sphere_min, box_leave: profiles/r02_e_final/lean_knob_sweep.txt)
+  PoolTuning pool_tune{40, 16, 24, 16, 16, 40};  // lean ray-pool kernel (refill_min, sphere_min, box_leave: profiles/r02_e_final/lean_knob_sweep.txt, middle of round 2)
   PoolTuning full_tune{20, 24, 32, 16, 24, 40};  // full-feature pool kernel (a service there also has hit records to move)
   PoolTuning sync_tune{20, 16, 32, 16, 16, 40};  // lock-step kernel (only run_ahead / run_ahead_min / gather_min matter there)
   int wg_per_cu = 0;                       // 0 = ask the occupancy API

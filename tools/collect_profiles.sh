@@ -7,6 +7,8 @@ tools/profile_kernel.sh ${tag}_book1 book1 "render_lean_pool<true, false" 480000
 tools/profile_kernel.sh ${tag}_book2 book2 "render_full_pool<1, true, false" 64000000 --spp 100 > $O/profile_book2.log 2>&1
 tools/profile_kernel.sh ${tag}_cornell cornell "render_full_sync<1, false, false" 9000000 > $O/profile_cornell.log 2>&1
 for k in book1 book2 cornell; do mkdir -p $O/$k; cp gpurun_out/${tag}_$k/* $O/$k/; done
+# the bench lines below take their instruction counts from THIS build's counters (bench.py reads profiles/current.json)
+printf '{\n "book1": "gpurun_out/%s/book1/pmc_summary.json",\n "book2": "gpurun_out/%s/book2/pmc_summary.json",\n "cornell": "gpurun_out/%s/cornell/pmc_summary.json"\n}\n' $tag $tag $tag > profiles/current.json
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --spp 500 --no-cpu-baseline > $O/bench_500spp.json 2>/dev/null
 python bench.py --bvh sah --no-cpu-baseline > $O/bench_sah.json 2>/dev/null
