@@ -2,7 +2,7 @@
 // path for the book-1 north-star workload.  Same arithmetic as rt_trace.h; the SCHEDULE is built for
 // CDNA4's 64-wide waves and 160 KB LDS:
 //
-//  * every wave owns a private pool of POOL = 144 path slots.  A slot holds a whole path state: the ray
+//  * every wave owns a private pool of POOL = 156 path slots.  A slot holds a whole path state: the ray
 //    (o, d) in LDS when the program leaves room (RAY_LDS), best hit, strength, bounce / sample counters
 //    and pixel as SoA rows in a per-wave region of global memory sized to stay in the L2s.
 //  * the wave's 64 lanes only TRAVERSE: a lane holds (o, d, 1/d, best, pc, current record) of one
@@ -70,9 +70,9 @@ RT_DEV T* uniform_ptr(T* p) {
 #define RT_GATED_SERVICE 1
 #endif
 #ifndef RT_POOL_SLOTS
-#define RT_POOL_SLOTS 144  // 8 global dwords x 144 slots x 4 096 waves = 2.4 MB per XCD: the slot rows stay in the 4 MB L2s
+#define RT_POOL_SLOTS 156  // what book-1's image leaves room for in LDS (36 B per slot and wave: 163 584 of 163 840 B); C2: 136 7.95 ms, 144 7.81, 148 7.77, 152 7.75, 156 7.72
 #endif
-constexpr uint32_t POOL = RT_POOL_SLOTS;           // path slots per wave: 64 in lanes + 80 waiting (a wait list reaches 64 while the lanes drain)
+constexpr uint32_t POOL = RT_POOL_SLOTS;           // path slots per wave: 64 in lanes + 92 waiting (a wait list reaches 64 while the lanes drain)
 constexpr uint32_t POOL_FIELDS = 17;     // dwords per slot (SoA: field f of slot j at [f * POOL + j]); 14 in chunk mode
 constexpr uint32_t WORK_BLOCK = 256;     // work items a wave reserves per global atomic (2048 cost 20 % on C2: ~6 blocks per wave = a coarse tail)
 constexpr uint32_t SLOT_NEED_PIXEL = 0xfffffffeu;  // best_pc marker: slot holds no ray yet
