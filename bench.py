@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="book1",
                     help="book1 = BASELINE.json's metric workload (default); book2 / cornell = configs[3] / configs[0]")
+    ap.add_argument("--bvh4", action="store_true",
+                    help="book1: traverse the 4-wide collapse of the reference Bvh (same image, other counters: not the headline)")
     ap.add_argument("--bvh", choices=["reference", "sah"], default="reference",
                     help="book1 only: 'reference' = Bvh::new's median split (bvh.rs:22-81, the parity mode and the "
                          "default); 'sah' = the surface-area-heuristic builder (SURVEY.md 8 f2: same image, fewer Aabb tests)")
@@ -148,6 +150,9 @@ def main():
     b = gpu.builder()
     objs, cam, _ = build_scene(pkg, b, nx, ny)
     scene = b.scene(objs, device=dev_index)
+    if args.bvh4:
+        scene.set_option("bvh4", 1)
+        wdesc = wdesc + " [traversed as 4-wide nodes: non-parity counters]"
     info = scene.info()
     info_lean = args.workload == "book1"
 
@@ -211,7 +216,7 @@ def main():
         kernel_name = {"book1": "rtg::render_lean_pool", "book2": "rtg::render_full_pool", "cornell": "rtg::render_full_sync"}[args.workload]
         kernel_s = avg_kernel_ms * 1e-3
         rank_samples = px_rank * spp
-        pmc, pmc_path = rl.find_profile(ROOT, args.workload if args.bvh == "reference" else args.workload + "_" + args.bvh)
+        pmc, pmc_path = rl.find_profile(ROOT, (args.workload if args.bvh == "reference" else args.workload + "_" + args.bvh) + ("_bvh4" if args.bvh4 else ""))
         if pmc is not None:
             roof = rl.valu_roofline(pmc, kernel_s, samples=rank_samples)
             roof["pmc_source"] = pmc_path

@@ -143,7 +143,9 @@ int rtg_scene_create(rtg_builder* b, const rtg_id* world, size_t n, int device, 
 void rtg_scene_destroy(rtg_scene* s);
 /* Scheduling / measurement switches of one scene handle -- kernel generation, cost-ordered work queue, pool
  * thresholds, workgroup size (names: DESIGN.md section 4 "Knobs").  None of them changes a bit of the result.  The
- * library reads no environment variable for these. */
+ * library reads no environment variable for these.  "bvh4" = 1 (scenes that are ONE Bvh of spheres; RTG_ERR_INVALID
+ * otherwise) traverses the reference's tree (bvh.rs:22-120) as 4-wide nodes: the same framebuffer, other
+ * rtg_stats.aabb_tests / prim_tests than the reference's walk. */
 int rtg_scene_set_option(rtg_scene* s, const char* name, int value);
 /* size of the flattened program (for DESIGN.md's byte accounting / tests) */
 int rtg_scene_info(const rtg_scene* s, uint32_t* n_instructions, uint32_t* n_materials,

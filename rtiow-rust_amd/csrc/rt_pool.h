@@ -284,6 +284,17 @@ struct PoolTuning {
 // ds_read2_b32 an unaligned pair needs); the offset is fixed per ray, so the swap costs no instruction per step.
 constexpr uint32_t LDS_BOX_BYTES = 56, LDS_SPHERE_BYTES = 24, LDS_END_BYTES = 8 + 56;
 constexpr uint32_t LDS_BOX_BIT = 0x80000000u;
+// 4-wide image (template parameter WIDE, option `bvh4`; built by rtg_api.hip build_wide_image; offsets relative to the image):
+//   NODE   208 B  dw0 parent node (WIDE_NO_PARENT: the root)   dw1 LDS_BOX_BIT | OP_BOX | level << 8 | children << 12 | leaf mask << 16
+//                 dw2-3 four child offsets / 8 (u16 each)       dw4-51 four boxes, each as the BOX record above: the three
+//                 (min, max) pairs, then the three (max, min) pairs (a lane reads ITS pair per axis with one ds_read_b64)
+//   SPHERE  32 B  dw0-5 as above                                dw6 parent node
+// A step tests a node's four boxes at once (the children's and grandchildren's boxes of the reference's binary node) with the
+// ray's CURRENT best and keeps the four results in 4 bits of a per-lane register (one nibble per level, <= 8 levels); the
+// children are then visited left to right, as the reference visits them.  A box tested earlier is tested against a best that
+// is no smaller than the reference's at that point, so every leaf the reference tests is tested here too, in the same order:
+// the same closest hit, the same image -- other counter values (more sphere tests, fewer dependent steps).
+constexpr uint32_t WIDE_NODE_BYTES = 208, WIDE_SPHERE_BYTES = 32, WIDE_NO_PARENT = 0xffffffffu;
 typedef __attribute__((address_space(3))) const char* lds_cptr;
 
 // byte offset of every record inside the image (host side, at scene creation); returns the image size (multiple of 16).
@@ -354,7 +365,7 @@ RT_DEV uint4 fetch_hi_global(const DevScene& sc, uint32_t idx) {  // byte-offset
 // from the winning SPHERE record (the flattener copies the material kind into its flag word).
 // HOT_LDS: the hot slot fields -- the ray (o, d) and (best, best_pc), see pool_lds_bytes -- live in LDS when the
 // program leaves room; the cold fields stay in the global SoA region.
-template <bool USE_LDS, bool COUNT, bool HOT_LDS>
+template <bool USE_LDS, bool COUNT, bool HOT_LDS, bool WIDE = false>
 __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void render_lean_pool(
     DevScene sc, const LaunchConsts* __restrict__ lc, float* __restrict__ out, uint32_t total_work, uint32_t* __restrict__ queue,
     unsigned long long* counters, PoolTuning tune, uint32_t* __restrict__ g_slots) {
@@ -368,7 +379,9 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
   const uint32_t staged = USE_LDS ? image + 16u * sc.n_mat : 0u;  // bytes
   uint32_t* s_words = reinterpret_cast<uint32_t*>(s_mem);
   const uint32_t pc0 = USE_LDS ? (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)s_mem : 0u;  // pc of record 0
-  if (USE_LDS) {
+  if (WIDE) {
+    for (uint32_t i = threadIdx.x; i < image / 4u; i += blockDim.x) s_words[i] = sc.lds_off[i];  // (the 4-wide image itself)
+  } else if (USE_LDS) {
     for (uint32_t i = threadIdx.x; i < n_prog; i += blockDim.x) {
       const uint4 l = sc.lo[i], h = sc.hi[i];
       uint32_t* r = s_words + (sc.lds_off[i] >> 2);
@@ -384,6 +397,8 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
         for (uint32_t k = 2; k < LDS_END_BYTES / 4u; k++) r[k] = 0u;
       }
     }
+  }
+  if (USE_LDS) {
     for (uint32_t i = threadIdx.x; i < sc.n_mat; i += blockDim.x) {
       const uint4 m = sc.mat[2u * i];
       uint32_t* r = s_words + (image >> 2) + 4u * i;
@@ -457,6 +472,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
   f32x2 cx = {0.f, 0.f}, cy = cx, cz = cx;
   uint32_t c_skip = 0, c_flags = 0xffu;
   uint32_t sgn_x = 0, sgn_y = 0, sgn_z = 0;  // staged: byte offset of this ray's plane pair inside each triple
+  uint32_t mstack = 0;                       // WIDE: per level 4 bits "this child's box was hit and the child is still to visit"
   Counts cnt = {0, 0, 0, 0};
   uint32_t total_draws = 0;
   // Per-sample trace (instrumented variant only, rtg_debug_samples on THIS kernel): counters[30] = base of the
@@ -508,6 +524,50 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           float end = rs_min(best, rs_min(rs_min(tx.y, ty.y), tz.y)); \
           pc = (end > start) ? pc + REC_BOX : c_skip; \
           RT_LOAD_REC(); \
+        }
+  // WIDE: continue at node `n_pc`: its next pending child (left to right), else up to its parent, else the program ends
+  auto wide_next = [&](uint32_t n_pc) {
+    for (;;) {
+      const uint4 h = lds_u4(n_pc);  // parent, flags, child offsets
+      const uint32_t lvl4 = ((h.y >> 8) & 0xfu) * 4u;
+      const uint32_t m = (mstack >> lvl4) & 0xfu;
+      if (m != 0u) {
+        const uint32_t c = (uint32_t)__builtin_ctz(m);
+        mstack &= ~(1u << (lvl4 + c));
+        const uint32_t pair = c < 2u ? h.z : h.w;
+        pc = pc0 + (((c & 1u) ? pair >> 16 : pair & 0xffffu) << 3);
+        c_flags = ((h.y >> (16u + c)) & 1u) ? RT_AS3(uint32_t, pc + 4u) : (LDS_BOX_BIT | (uint32_t)OP_BOX);
+        return;
+      }
+      if (h.x == WIDE_NO_PARENT) {
+        c_flags = OP_END;
+        return;
+      }
+      n_pc = pc0 + h.x;
+    }
+  };
+  // WIDE: one step at a node: Aabb::hit (aabb.rs:16-27, the arithmetic of rt_full_traverse.inc) for its <= 4 boxes at once
+#define RT_WIDE_STEP() \
+        if (RT_IS_BOX()) { \
+          const uint4 h_ = lds_u4(pc); \
+          const uint32_t nch_ = (h_.y >> 12) & 7u; \
+          uint32_t m_ = 0; \
+          _Pragma("unroll") for (uint32_t k_ = 0; k_ < 4u; k_++) { \
+            const f32x2 px_ = RT_AS3(f32x2, pc + 8u + 48u * k_ + sgn_x); \
+            const f32x2 py_ = RT_AS3(f32x2, pc + 8u + 48u * k_ + sgn_y); \
+            const f32x2 pz_ = RT_AS3(f32x2, pc + 8u + 48u * k_ + sgn_z); \
+            const float ax = (px_.x - o.x) * inv.x, bx = (px_.y - o.x) * inv.x; \
+            const float ay = (py_.x - o.y) * inv.y, by = (py_.y - o.y) * inv.y; \
+            const float az = (pz_.x - o.z) * inv.z, bz = (pz_.y - o.z) * inv.z; \
+            const float start = rs_max(t_near, rs_max(rs_max(ax, ay), az)); \
+            const float end = rs_min(best, rs_min(rs_min(bx, by), bz)); \
+            m_ |= (end > start ? 1u : 0u) << k_; \
+          } \
+          m_ &= (1u << nch_) - 1u; \
+          if (COUNT) cnt.aabb += nch_; \
+          const uint32_t lvl4_ = ((h_.y >> 8) & 0xfu) * 4u; \
+          mstack = (mstack & ~(0xfu << lvl4_)) | (m_ << lvl4_); \
+          wide_next(pc); \
         }
   for (;;) {
     uint32_t op = have_ray ? (c_flags & 0xffu) : 0xffu;
@@ -796,7 +856,11 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
             sgn_x = inv.x < 0.f ? 32u : 8u, sgn_y = inv.y < 0.f ? 40u : 16u, sgn_z = inv.z < 0.f ? 48u : 24u;  // aabb.rs:20-23
             pc = pc0, best = F32_MAX, best_pc = NO_HIT, best_flags = 0;
             if (COUNT) tr_a0 = cnt.aabb, tr_p0 = cnt.prim;
-            RT_LOAD_REC();
+            if (WIDE) {
+              c_flags = LDS_BOX_BIT | (uint32_t)OP_BOX, mstack = 0u;  // the root node (offset 0 of the image)
+            } else {
+              RT_LOAD_REC();
+            }
             have_ray = true;
           }
           t_count -= got;
@@ -824,6 +888,9 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
       uint32_t n_now;
       do {
         if (COUNT) n_box_it++;
+        if (WIDE) {
+          RT_WIDE_STEP();
+        } else {
         RT_BOX_STEP();
 #if RT_BOX_UNROLL >= 2
         RT_BOX_STEP();  // lanes that left the BOX state sit this one out; the schedule check runs every other step
@@ -834,6 +901,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
 #if RT_BOX_UNROLL >= 4
         RT_BOX_STEP();
 #endif
+        }
         n_now = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(RT_IS_BOX()));
         if (COUNT) n_box_lanes += n_now;
       } while (n_now > floor_lanes);
@@ -851,8 +919,12 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           best_pc = pc;
           best_flags = c_flags;
         }
-        pc += REC_SPHERE;
-        RT_LOAD_REC();
+        if (WIDE) {
+          wide_next(pc0 + RT_AS3(uint32_t, pc + 24u));  // back to the parent node
+        } else {
+          pc += REC_SPHERE;
+          RT_LOAD_REC();
+        }
       }
       if (COUNT) t_sph += RT_TICK() - t_mark;
     }

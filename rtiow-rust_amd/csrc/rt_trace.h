@@ -13,10 +13,11 @@ struct DevScene {
   const uint4* tex;          // 2 packets per texture
   const float4* perlin_vecs; // 256 gradients (perlin.rs VECS)
   const uint8_t* perlin_perm;// PERM_X | PERM_Y | PERM_Z, 3 x 256
-  const uint32_t* lds_off;   // lean programs: byte offset of every record inside the LDS image (rt_pool.h)
+  const uint32_t* lds_off;   // lean programs: byte offset of every record inside the LDS image (rt_pool.h); launches of the
+                             // 4-wide variant (rt_pool.h WIDE) pass the words of the 4-wide image here
   uint32_t n_prog;
   uint32_t n_mat;
-  uint32_t lds_image_bytes;  // size of that image, 0 = the program has none
+  uint32_t lds_image_bytes;  // size of that image, 0 = the program has none (WIDE launches: size of the 4-wide image)
 };
 
 struct DevCamera {  // camera.rs:6-15

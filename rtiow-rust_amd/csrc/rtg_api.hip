@@ -13,6 +13,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -157,7 +158,7 @@ struct rtg_scene {
   uint32_t features = 0;
   uint32_t n_prog = 0, n_mat = 0, n_tex = 0;
   uint64_t bytes = 0;
-  void* buffers[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  void* buffers[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   unsigned long long* d_counters = nullptr;  // [0..4] N/P/H/rays/draws, [7] = work-queue head (persistent kernel)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t own_stream = nullptr;  // rtg_par_cast_multi: this scene's launch stream (created on first use)
@@ -180,6 +181,8 @@ struct rtg_scene {
   int verbose = 0;
   int window = -1;             // full-feature kernel: records of the program staged in LDS (-1 = as many as fit)
   int ray_lds = 1;             // 0: all slot fields in global memory
+  int bvh4 = 0;                // 1: traverse the 4-wide collapse of the Bvh (same image, other counters; needs wide_bytes)
+  uint32_t wide_bytes = 0;     // size of the 4-wide image in buffers[7], 0 = the scene has none
   int sync_full = -1;          // full-feature scenes on the pool-free lock-step kernel (rt_sync_full.h): -1 = when the program holds no BOX record, 0 / 1 = never / always
   uint32_t n_box = 0;          // BOX records of the flat program
   int lpt = 2;                 // RTG_LPT=0: natural order throughout; 1 / 2 = LptQueue::mode
@@ -248,12 +251,17 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
   hipError_t e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream);  // re-initialise every call
   if (e != hipSuccess) return e;
   const size_t lds_limit = 160 * 1024;
-  const uint32_t image = s->dev.lds_image_bytes;
+  const bool wide = s->bvh4 && s->wide_bytes != 0;
+  const uint32_t image = wide ? s->wide_bytes : s->dev.lds_image_bytes;
+  DevScene dev = s->dev;
+  if (wide) dev.lds_off = (const uint32_t*)s->buffers[7], dev.lds_image_bytes = s->wide_bytes;  // the WIDE kernel's reading of these two
   bool use_lds = image != 0 && pool_lds_bytes(image, s->n_mat, waves, true, false) <= lds_limit;
+  if (wide && !use_lds) return hipErrorNotSupported;
   bool ray_lds = s->ray_lds && pool_lds_bytes(image, s->n_mat, waves, use_lds, true) <= lds_limit;
   size_t lds = pool_lds_bytes(image, s->n_mat, waves, use_lds, ray_lds);
   void (*kernel)(DevScene, const LaunchConsts*, float*, uint32_t, uint32_t*, unsigned long long*, PoolTuning, uint32_t*);
-  if (ray_lds) kernel = use_lds ? render_lean_pool<true, COUNT, true> : render_lean_pool<false, COUNT, true>;
+  if (wide) kernel = ray_lds ? render_lean_pool<true, COUNT, true, true> : render_lean_pool<true, COUNT, false, true>;
+  else if (ray_lds) kernel = use_lds ? render_lean_pool<true, COUNT, true> : render_lean_pool<false, COUNT, true>;
   else kernel = use_lds ? render_lean_pool<true, COUNT, false> : render_lean_pool<false, COUNT, false>;
   e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -282,7 +290,7 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
     }
   }
   hipLaunchKernelGGL(write_launch_consts, dim3(1), dim3(1), 0, stream, s->d_consts, LaunchConsts{cam, d, cm});
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(bt), lds, stream, s->dev, (const LaunchConsts*)s->d_consts, d_out, (uint32_t)total_work, queue,
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(bt), lds, stream, dev, (const LaunchConsts*)s->d_consts, d_out, (uint32_t)total_work, queue,
                      s->d_counters, s->pool_tune, s->d_slots);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
@@ -291,6 +299,75 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
     e = hipGetLastError();
   }
   return e;
+}
+
+// The 4-wide image of a lean program that is ONE Bvh over spheres (rt_pool.h WIDE; option `bvh4`): every node record holds
+// the boxes of up to four GRANDCHILDREN of a node of the reference's tree (bvh.rs:22-81), in the reference's left-to-right
+// order, so that a traversal step tests four boxes at once and the leaves are still met in the reference's order.  Returns
+// false when the program has another shape (list-level objects, bare leaves, more than 8 levels).
+static bool build_wide_image(const Packet* lo, const Packet* hi, size_t n, std::vector<uint32_t>& out) {
+  struct T { uint32_t box; int left, right; uint32_t sphere; };  // left < 0: a leaf (box + sphere)
+  std::vector<T> nodes;
+  auto op_of = [&](size_t i) { return hi[i].w[3] & 0xffu; };
+  if (n < 4 || op_of(n - 1) != OP_END || op_of(0) != OP_BOX || hi[0].w[2] != n - 1) return false;
+  bool ok = true;
+  std::function<int(size_t, size_t&)> parse = [&](size_t i, size_t& end) -> int {
+    if (i >= n || op_of(i) != OP_BOX) { ok = false; end = i + 1; return -1; }
+    end = hi[i].w[2];
+    const int id = (int)nodes.size();
+    nodes.push_back(T{(uint32_t)i, -1, -1, 0});
+    if (op_of(i + 1) == OP_SPHERE) {
+      if (end != i + 2) ok = false;
+      nodes[id].sphere = (uint32_t)(i + 1);
+      return id;
+    }
+    size_t e1 = 0, e2 = 0;
+    const int l = parse(i + 1, e1);
+    if (!ok || e1 >= end) { ok = false; return id; }
+    const int r = parse(e1, e2);
+    if (e2 != end) ok = false;
+    nodes[id].left = l, nodes[id].right = r;
+    return id;
+  };
+  size_t end0 = 0;
+  const int root = parse(0, end0);
+  if (!ok || root < 0 || nodes[root].left < 0) return false;
+  out.clear();
+  auto alloc = [&](uint32_t bytes) { const uint32_t at = (uint32_t)out.size() * 4u; out.resize(out.size() + bytes / 4u, 0u); return at; };
+  std::function<uint32_t(int, uint32_t, uint32_t)> emit = [&](int t, uint32_t parent, uint32_t level) -> uint32_t {
+    if (level > 7u) { ok = false; return 0; }
+    const uint32_t at = alloc(WIDE_NODE_BYTES);
+    int entry[4];
+    uint32_t n_ch = 0;
+    for (int x : {nodes[t].left, nodes[t].right}) {
+      if (nodes[x].left < 0) entry[n_ch++] = x;
+      else entry[n_ch++] = nodes[x].left, entry[n_ch++] = nodes[x].right;
+    }
+    uint32_t child[4] = {0, 0, 0, 0}, leafmask = 0;
+    for (uint32_t k = 0; k < n_ch; k++) {
+      const T e = nodes[entry[k]];
+      const Packet bl = lo[e.box], bh = hi[e.box];  // (min.x, max.x, min.y, max.y) (min.z, max.z, ..)
+      uint32_t* b = out.data() + at / 4u + 4u + 12u * k;  // (min, max) pairs, then (max, min) pairs: rt_pool.h
+      b[0] = bl.w[0], b[1] = bl.w[1], b[2] = bl.w[2], b[3] = bl.w[3], b[4] = bh.w[0], b[5] = bh.w[1];
+      b[6] = bl.w[1], b[7] = bl.w[0], b[8] = bl.w[3], b[9] = bl.w[2], b[10] = bh.w[1], b[11] = bh.w[0];
+      if (e.left < 0) {
+        const uint32_t sp = alloc(WIDE_SPHERE_BYTES);
+        uint32_t* r = out.data() + sp / 4u;
+        r[0] = hi[e.sphere].w[2], r[1] = hi[e.sphere].w[3];
+        r[2] = lo[e.sphere].w[0], r[3] = lo[e.sphere].w[1], r[4] = lo[e.sphere].w[2], r[5] = lo[e.sphere].w[3];
+        r[6] = at, r[7] = 0u;
+        child[k] = sp, leafmask |= 1u << k;
+      } else {
+        child[k] = emit(entry[k], at, level + 1u);
+      }
+    }
+    uint32_t* h = out.data() + at / 4u;
+    h[0] = parent, h[1] = LDS_BOX_BIT | OP_BOX | (level << 8) | (n_ch << 12) | (leafmask << 16);
+    h[2] = (child[0] >> 3) | ((child[1] >> 3) << 16), h[3] = (child[2] >> 3) | ((child[3] >> 3) << 16);
+    return at;
+  };
+  emit(root, WIDE_NO_PARENT, 0u);
+  return ok && out.size() * 4u < 512u * 1024u;
 }
 
 static hipError_t grow(void** buf, size_t* have, size_t need) {
@@ -776,6 +853,14 @@ int rtg_scene_create(rtg_builder* b, const rtg_id* world, size_t n, int device, 
       return rc;
     }
     s->dev.lds_off = (const uint32_t*)s->buffers[6];
+    std::vector<uint32_t> wide;
+    if (build_wide_image(fs.lo.data(), fs.hi.data(), fs.hi.size(), wide)) {
+      if ((rc = upload(&s->buffers[7], wide.data(), wide.size() * sizeof(uint32_t), &s->bytes))) {
+        rtg_scene_destroy(s);
+        return rc;
+      }
+      s->wide_bytes = (uint32_t)(wide.size() * sizeof(uint32_t));
+    }
   }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->num_cus = prop.multiProcessorCount;
@@ -804,6 +889,10 @@ int rtg_scene_set_option(rtg_scene* s, const char* name, int value) {
   else if (k == "lpt_deep") s->lpt_deep = value;
   else if (k == "lpt_shift") s->lpt_shift = std::min(6, std::max(0, value));
   else if (k == "ray_lds") s->ray_lds = value;
+  else if (k == "bvh4") {
+    if (value && !s->wide_bytes) return fail(RTG_ERR_INVALID, "bvh4: the scene is not one Bvh of spheres (no 4-wide image)");
+    s->bvh4 = value;
+  }
   else if (k == "sync") s->sync_full = value;
   else if (k == "block") s->pool_threads = s->full_threads = value;
   else if (k == "wg_per_cu") s->wg_per_cu = value;

@@ -424,3 +424,29 @@ def test_output_stage_tonemap(pkg, gpu, oracle):
     sg, cam, nx, ny, ns = build_case(pkg, gpu, "cornell")
     img = sg.par_cast(cam, nx, ny, ns)
     assert np.array_equal(gpu.tonemap(img), pkg.ppm.to_u8(img).astype(np.uint8))
+
+
+@pytest.mark.gpu
+def test_bvh4_mode_renders_the_same_image(pkg, gpu, oracle):
+    """Non-parity traversal mode: the reference Bvh collapsed to 4-wide nodes.  Boxes are tested earlier
+    (against a `best` that is no smaller than the reference's), leaves in the reference's order: same closest hits, same
+    image, same rays / shaded hits / draws -- other Aabb / sphere test counts, fewer dependent steps."""
+    nx, ny, ns = 120, 80, 8
+    bo = oracle.builder()
+    wo, cam_o, _ = pkg.scenes.random_scene(bo, nx, ny)
+    img_o, st_o = bo.scene(wo).par_cast(cam_o, nx, ny, ns, stats=True)
+    bg = gpu.builder()
+    wg, cam_g, _ = pkg.scenes.random_scene(bg, nx, ny)
+    sg = bg.scene(wg)
+    sg.set_option("bvh4", 1)
+    img_g, st_g = sg.par_cast(cam_g, nx, ny, ns, stats=True)
+    assert_bit_equal(img_g, img_o, "bvh4, instrumented variant")
+    assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns), img_o, "bvh4, timed variant")
+    for k in ("shaded_hits", "rays", "draws"):
+        assert st_g[k] == st_o[k], (k, st_g[k], st_o[k])
+    assert st_g["prim_tests"] >= st_o["prim_tests"]          # a superset of the reference's leaves
+    # a scene that is not ONE Bvh of spheres has no 4-wide image: the option is refused, nothing is rendered differently
+    b2 = gpu.builder()
+    w2, _, _ = pkg.scenes.cornell_box_scene(b2, 30, 30)
+    with pytest.raises(pkg.capi.RtError):
+        b2.scene(w2).set_option("bvh4", 1)

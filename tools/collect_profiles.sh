@@ -12,6 +12,7 @@ printf '{\n "book1": "gpurun_out/%s/book1/pmc_summary.json",\n "book2": "gpurun_
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --spp 500 --no-cpu-baseline > $O/bench_500spp.json 2>/dev/null
 python bench.py --bvh sah --no-cpu-baseline > $O/bench_sah.json 2>/dev/null
+python bench.py --bvh4 --no-cpu-baseline > $O/bench_bvh4.json 2>/dev/null
 python bench.py --workload cornell > $O/bench_cornell_c1.json 2>/dev/null
 python bench.py --workload book2 --steps 3 > $O/bench_book2_c4.json 2>/dev/null
 RTG_VERBOSE=1 python tools/time_scenes.py book1 1200 800 50 2>&1 | grep "^\[rtg\] wave\|^\[rtg\] pool sched" | sort -u > $O/schedule_book1.txt
