@@ -5,15 +5,17 @@
 // Differences from the lean kernel:
 //  * the hit record (p, normal, material) is built at hit time and carried in registers, because it
 //    has to travel back through the enclosing POPs (object.rs:279-282,365-369);
-//  * paths have no home slot: their state MOVES through three dense per-wave stacks in global memory -- T (rays to
+//  * paths have no home slot: their state MOVES through four dense per-wave stacks in global memory -- T (rays to
 //    traverse: origin, direction, time, strength, bounces, sample, pixel), S and X (finished rays to shade without / with
-//    a texture lookup: hit record, direction, time, draws made, strength, bounces, sample, pixel).  Every push goes to
-//    consecutive positions ([field][position] rows, so a wave's push is whole cache lines) and every pop takes the top:
-//    what was written last is read next, from L2.  The lanes carry strength / bounces / sample / pixel in registers
-//    while they traverse;
+//    a texture lookup: hit record, direction, time, draws made, strength, bounces, sample, pixel) and N (paths that ended
+//    and ask for their successor: sample, pixel).  Every push goes to consecutive positions ([field][position] rows, so a
+//    wave's push is whole cache lines) and every pop takes the top: what was written last is read next, from L2.  The
+//    lanes carry strength / bounces / sample / pixel in registers while they traverse;
+//  * three kinds of 64-wide passes: scatter (S), textured scatter (X), camera rays (N: next sample / next work item);
 //  * every non-BOX record (SPHERE, RECT, PUSH, POP, MEDIUM) is a "slow op": lanes park on it and a slow
 //    pass executes one record per parked lane once enough lanes wait (or no BOX lane is left);
-//  * the transform stack (<= 4 saved rays) lives in a per-wave, lane-interleaved global scratch;
+//  * the transform stack (<= 4 saved rays): level 0 in registers, deeper levels in a per-wave, lane-interleaved global
+//    scratch;
 //  * a medium draws from the event's RNG stream by index (event_draw), and the number of draws made
 //    during traversal travels with the path so that Material::scatter continues the stream where
 //    traversal left it (draw order of SURVEY 8a);
@@ -56,11 +58,11 @@ __device__ __attribute__((noinline)) float event_draw_f32(uint64_t seed, uint32_
 }
 
 // PROG: 0 = program fetched from global memory (L1/L2), 1 = whole program staged in LDS, 2 = an LDS
-// window over the first `window` records (depth-first order, so it holds whole leading subtrees: book-2's
-// 199 KB program keeps its floor Bvh and most top-level objects in LDS) and global memory for the rest.
+// window over the first `window` records (depth-first order, so it holds whole leading subtrees) and global memory for the
+// rest (book-2's 4 213 records = 134.8 KB fit whole).
 #ifndef RT_FULL_TEX_THREADS
-#define RT_FULL_TEX_THREADS 1024  // the textured variant wants ~142 VGPRs; capped at 128 it spills ~25 of them to scratch but
-                                  // runs 16 instead of 12 waves per CU: measured 4 % faster on book-2 (768 = no spills)
+#define RT_FULL_TEX_THREADS 1024  // 16 waves per CU; the textured variant allocates 120-128 VGPRs without a spill (round 1: ~142
+                                  // wanted, 25 spilled -- and still 4 % faster than 12 waves at 768 threads)
 #endif
 // ---- stack access: `qr` = the wave's stack space
 RT_DEV uint32_t f2u(float f) { return __float_as_uint(f); }
