@@ -8,7 +8,9 @@ A "step" = one full par_cast of the workload into a framebuffer resident in HBM.
           scaling, as north_star states it ("1200x800x500spp reported at 1/2/4/8 MI355X").
           `--workload book2`: N = 1 renders configs[3] (C4, 800x800x1000), N > 1 the fixed frame of configs[4]
           (C5, 800x800x5000).  `--scaling weak` keeps the per-GPU samples fixed instead (spp = N x the N = 1 spp).
-Launch for N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
+Launch for N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N   (one rank per GPU)
+              or plain `python bench.py --gpus N`, which starts those N ranks itself.  Either way WORLD_SIZE must equal
+              --gpus and the host must show N GPUs, else the run exits non-zero instead of reporting another N.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -86,6 +88,30 @@ def cpu_baseline(pkg, build_scene, nx, ny, target_seconds=12.0, max_spp=1000):
                     "(same row granularity as lib.rs:326-330) on the cores the cgroup quota allows"}
 
 
+def self_launch(n, backend):
+    """`python bench.py --gpus N` without a launcher: run this file as N ranks under torch.distributed.run (one rank per
+    GPU, rendezvous on 127.0.0.1) and pass the JSON line and the exit code through.  Refuses, non-zero, when the host has
+    fewer than N GPUs (the gloo TEST hook may put several ranks on one GPU)."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < 1:
+        print("bench.py needs a GPU: the hot path has no CPU fallback", file=sys.stderr)
+        return 2
+    if backend == "nccl" and have < n:
+        print("bench.py: --gpus %d but this host shows %d GPU(s): one rank per GPU over RCCL" % (n, have), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,20 +136,33 @@ def main():
                     help="rank 0 also renders the frame unsharded and checks the reduced frame bit-for-bit")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    # RTG_BENCH_BACKEND=gloo is a TEST hook: it lets the N>1 code path run with several ranks on ONE GPU
+    # (RCCL refuses two ranks per device); the framebuffer is then reduced through host memory.
+    backend = os.environ.get("RTG_BENCH_BACKEND", "nccl")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Plain `python bench.py --gpus N`: launch ourselves as N ranks, one per GPU (the driver's own
+        # `python -m torch.distributed.run ... bench.py --gpus N` arrives with WORLD_SIZE set and skips this).
+        sys.exit(self_launch(args.gpus, backend))
+
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:   # never report another N than the one asked for
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d: launch with --nproc-per-node %d (or plain "
+                         "`python bench.py --gpus %d`, which launches its own ranks)" % (args.gpus, world, args.gpus, args.gpus))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    # RTG_BENCH_BACKEND=gloo is a TEST hook: it lets the N>1 code path run with several ranks on ONE GPU
-    # (RCCL refuses two ranks per device); the framebuffer is then reduced through host memory.
-    backend = os.environ.get("RTG_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: --gpus %d but this host shows %d GPU(s): one rank per GPU over RCCL"
+                         % (world, torch.cuda.device_count()))
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)

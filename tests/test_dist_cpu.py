@@ -42,3 +42,17 @@ def test_two_rank_gloo_reduce_equals_single_frame(tmp_path, pkg, oracle):
         assert p.wait(timeout=300) == 0
     scene, cam, nx, ny, ns = build_case(pkg, oracle, "book1", 64, 48)
     assert_bit_equal(np.load(out), scene.par_cast(cam, nx, ny, ns), "2-rank sharded frame")
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    """bench.py never reports another N than --gpus asks for (round 2: `bench.py --gpus 8` run as ONE process rendered
+    the 1-GPU frame and printed n_gpus: 1).  Checked before any GPU is touched, so it runs here."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    # without a launcher it starts its own ranks -- and refuses when the host does not have N GPUs (none here)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -392,6 +392,37 @@ def test_bench_multi_rank_path_on_one_gpu(tmp_path, scaling):
         assert 0.0 < line["roofline"]["frac"] <= 1.0
 
 
+def test_bench_gpus_flag_is_self_sufficient(tmp_path):
+    """`python bench.py --gpus N` WITHOUT a launcher starts its own N ranks (torch.distributed.run, one per GPU) and reports
+    n_gpus == N; it never reports another N than the one asked for: with fewer GPUs than ranks (RCCL: one rank per device)
+    and with a WORLD_SIZE that contradicts --gpus it exits non-zero and prints no JSON line."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, "bench.py")
+    small = ["--steps", "1", "--warmup", "0", "--nx", "160", "--ny", "96", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    # (a) plain launch, 2 ranks on the one GPU of this box through the gloo test hook
+    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--verify", "--spp", "20"] + small, env=dict(env, RTG_BENCH_BACKEND="gloo"),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["verified_bit_exact_vs_unsharded"] is True
+    # (b) more ranks than GPUs over RCCL: refused before anything is rendered
+    n_too_many = torch.cuda.device_count() + 7
+    out = subprocess.run([sys.executable, bench, "--gpus", str(n_too_many)] + small, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and "GPU(s)" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    # (c) a launcher that disagrees with --gpus (the silent N = 1 of round 2: `bench.py --gpus 8` run as one process
+    # printed n_gpus: 1): WORLD_SIZE = 1 with --gpus 2
+    out = subprocess.run([sys.executable, bench, "--gpus", "2"] + small, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and "WORLD_SIZE" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
 def test_degenerate_inputs(pkg, gpu, oracle):
     """Empty world (lib.rs:100: every ray misses -> black), ranks that own no tile, 1x1 images, ns = 1."""
     S = pkg.scenes
