@@ -176,6 +176,14 @@ int rtg_par_cast_device(rtg_scene* s, const rtg_camera* camera, const rtg_params
 int rtg_par_cast_multi(rtg_scene* const* scenes, int n_scenes, const rtg_camera* camera,
                        const rtg_params* params, float* out_rgb, rtg_stats* stats_or_null);
 
+/* Forget the multi-GPU state of the library: destroy the cached RCCL communicators (ncclCommDestroy), unload librccl,
+ * and choose the library the NEXT rtg_par_cast_multi loads: a path / soname, or NULL for the default search (an already
+ * loaded librccl first, then librccl.so.1 / librccl.so / /opt/rocm/lib/librccl.so.1).  A library that cannot be loaded makes
+ * rtg_par_cast_multi return RTG_ERR_DEVICE with dlopen's reason.  *n_reduces (may be NULL) receives the number of
+ * ncclReduce calls issued since the last reset.  Scene option "force_rccl" = 1 sends rtg_par_cast_multi through the RCCL
+ * collective even when all handles sit on ONE device (a clique of one), so that one-GPU hosts exercise the same code. */
+int rtg_multi_reset(const char* rccl_library_or_null, uint64_t* n_reduces_or_null);
+
 /* ---- output stage -------------------------------------------------------------------------- */
 /* print_ppm's per-channel quantisation (lib.rs:348-356): sqrt gamma, `(255.99 * x) as i32` (saturating,
  * NaN -> 0), clamped to 0..=255.  n floats in, n bytes out; both HOST pointers, computed on `device`.

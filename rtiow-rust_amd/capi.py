@@ -55,6 +55,10 @@ def make_params(nx, ny, ns, seed=0xDEADBEEF, max_bounces=50, t_near=0.001, tile_
     return p
 
 
+# error codes of include/rtiow_gpu.h
+ERR_INVALID, ERR_EMPTY_BVH, ERR_NAN, ERR_RANGE, ERR_UNSUPPORTED, ERR_DEVICE = -1, -2, -3, -4, -5, -6
+
+
 class RtError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("rt error %d: %s" % (code, msg))
@@ -73,7 +77,7 @@ ABI_SYMBOLS = [
     "material_isotropic", "object_sphere", "object_rect", "object_flip_normals", "object_translate",
     "object_scale", "object_rotate_y", "object_and", "object_rect_prism", "object_linear_move",
     "object_constant_medium", "object_bvh", "object_bvh_sah", "camera_look", "scene_create", "scene_destroy",
-    "scene_set_option", "scene_info", "par_cast", "par_cast_device", "par_cast_multi", "debug_hit_top", "debug_samples", "debug_math", "debug_flatten", "tonemap", "tonemap_device",
+    "scene_set_option", "scene_info", "par_cast", "par_cast_device", "par_cast_multi", "multi_reset", "debug_hit_top", "debug_samples", "debug_math", "debug_flatten", "tonemap", "tonemap_device",
 ]
 
 
@@ -133,6 +137,7 @@ class Backend:
                                        C.c_void_p, C.POINTER(Stats)])
         f("par_cast_multi", C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Camera), C.POINTER(Params), c_f32p,
                                       C.POINTER(Stats)])
+        f("multi_reset", C.c_int, [C.c_char_p, C.POINTER(C.c_uint64)])
         f("debug_flatten", C.c_int, [C.c_void_p, c_u32p, C.c_size_t, c_u32p, c_u32p, c_u32p, C.c_size_t])
         f("tonemap_device", C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p])
 
@@ -181,6 +186,13 @@ class Backend:
         self.check(self._par_cast_multi(arr, len(scenes), C.byref(camera), C.byref(p), out.ctypes.data_as(c_f32p),
                                         C.byref(st)))
         return (out, st.as_dict()) if stats else out
+
+    def multi_reset(self, rccl_library=None):
+        """rtg_multi_reset: drop the cached RCCL communicators, unload librccl, choose the library to load next (None =
+        default search).  Returns the number of ncclReduce calls issued since the last reset."""
+        n = C.c_uint64(0)
+        self.check(self._multi_reset(rccl_library.encode() if rccl_library else None, C.byref(n)))
+        return n.value
 
     def tonemap(self, img, device=0):
         """print_ppm's sqrt-gamma + `(255.99 * x) as i32` clamp (lib.rs:348-356) -> uint8 array of img's shape."""
@@ -337,7 +349,7 @@ class Scene:
     # measurement / test hook: RTG_<OPTION>=<int> in the environment of the PYTHON process becomes
     # rtg_scene_set_option(scene, "<option>", <int>) -- the library itself reads no environment variable
     ENV_OPTIONS = ("kernel", "chunks", "lpt", "lpt_phase1", "lpt_deep", "lpt_shift", "ray_lds", "sync", "block", "wg_per_cu", "window",
-                   "box_leave", "refill_min", "gather_min", "run_ahead", "run_ahead_min", "sphere_min", "verbose", "bvh4")
+                   "box_leave", "refill_min", "gather_min", "run_ahead", "run_ahead_min", "sphere_min", "verbose", "bvh4", "force_rccl")
 
     def set_option(self, name, value):
         self.be.check(self.be._scene_set_option(self.h, name.encode(), int(value)))

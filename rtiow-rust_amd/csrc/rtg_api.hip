@@ -181,6 +181,7 @@ struct rtg_scene {
   int verbose = 0;
   int window = -1;             // full-feature kernel: records of the program staged in LDS (-1 = as many as fit)
   int ray_lds = 1;             // 0: all slot fields in global memory
+  int force_rccl = 0;          // rtg_par_cast_multi: run the RCCL reduce even over ONE distinct device (a clique of one)
   int bvh4 = 0;                // 1: traverse the 4-wide collapse of the Bvh (same image, other counters; needs wide_bytes)
   uint32_t wide_bytes = 0;     // size of the 4-wide image in buffers[7], 0 = the scene has none
   int sync_full = -1;          // full-feature scenes on the pool-free lock-step kernel (rt_sync_full.h): -1 = when the program holds no BOX record, 0 / 1 = never / always
@@ -256,7 +257,7 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
   DevScene dev = s->dev;
   if (wide) dev.lds_off = (const uint32_t*)s->buffers[7], dev.lds_image_bytes = s->wide_bytes;  // the WIDE kernel's reading of these two
   bool use_lds = image != 0 && pool_lds_bytes(image, s->n_mat, waves, true, false) <= lds_limit;
-  if (wide && !use_lds) return hipErrorNotSupported;
+  if (wide && !use_lds) return hipErrorNotSupported;  // (rtg_scene_set_option refuses bvh4 for images that do not fit)
   bool ray_lds = s->ray_lds && pool_lds_bytes(image, s->n_mat, waves, use_lds, true) <= lds_limit;
   size_t lds = pool_lds_bytes(image, s->n_mat, waves, use_lds, ray_lds);
   void (*kernel)(DevScene, const LaunchConsts*, float*, uint32_t, uint32_t*, unsigned long long*, PoolTuning, uint32_t*);
@@ -891,10 +892,16 @@ int rtg_scene_set_option(rtg_scene* s, const char* name, int value) {
   else if (k == "ray_lds") s->ray_lds = value;
   else if (k == "bvh4") {
     if (value && !s->wide_bytes) return fail(RTG_ERR_INVALID, "bvh4: the scene is not one Bvh of spheres (no 4-wide image)");
+    if (value && pool_lds_bytes(s->wide_bytes, s->n_mat, (uint32_t)s->pool_threads / 64u, true, false) > 160 * 1024)
+      return fail(RTG_ERR_INVALID, "bvh4: the 4-wide image does not fit a CU's 160 KB of LDS (the 4-wide walk only exists LDS-staged)");
     s->bvh4 = value;
   }
+  else if (k == "force_rccl") s->force_rccl = value;
   else if (k == "sync") s->sync_full = value;
-  else if (k == "block") s->pool_threads = s->full_threads = value;
+  else if (k == "block") {
+    if (value < 64 || value > 1024 || value % 64) return fail(RTG_ERR_INVALID, "block: a multiple of 64 in [64, 1024]");
+    s->pool_threads = s->full_threads = value;
+  }
   else if (k == "wg_per_cu") s->wg_per_cu = value;
   else if (k == "verbose") s->verbose = value;                  // print launch geometry / schedule statistics to stderr
   else if (k == "window") s->window = value;                    // full-feature kernel: records staged in LDS, -1 = automatic
@@ -1050,34 +1057,47 @@ int rtg_par_cast(rtg_scene* s, const rtg_camera* camera, const rtg_params* param
 }
 
 // ---- single-process multi-GPU par_cast ---------------------------------------------------
-// RCCL is dlopen()ed on first use with more than one distinct device, so librtiow_gpu.so carries no link-time
-// dependency on it and one-GPU hosts never load it.
+// RCCL is dlopen()ed on first use (more than one distinct device, or the `force_rccl` option), so librtiow_gpu.so carries
+// no link-time dependency on it and one-GPU hosts never load it.
 namespace {
 struct Rccl {
   void* lib = nullptr;
+  std::string path;  // rtg_multi_reset: the library to load instead of the default search ("" = default)
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
-  std::map<std::vector<int>, std::vector<ncclComm_t>> comms;  // one clique per device list, created once
+  std::map<std::vector<int>, std::vector<ncclComm_t>> comms;  // one clique per device list, created once, destroyed by rtg_multi_reset
+  uint64_t n_reduces = 0;                                      // ncclReduce calls issued (rtg_multi_reset reports and clears it)
   std::mutex mu;
 };
 Rccl g_rccl;
 
+// (g_rccl.mu held)
 bool rccl_load(std::string* why) {
   if (g_rccl.lib) return true;
-  // an already-loaded librccl (e.g. the one a host framework ships) first, then the ROCm installation's
-  const char* names[] = {"librccl.so", "librccl.so.1"};
   void* h = nullptr;
-  for (const char* n : names)
-    if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
-  if (!h)
-    for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-      if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+  std::string tried;
+  auto attempt = [&](const char* n, int flags) {
+    if (h) return;
+    (void)dlerror();
+    h = dlopen(n, flags);
+    if (!h && !(flags & RTLD_NOLOAD)) {
+      const char* e = dlerror();  // ONE call: dlerror() clears the message it returns
+      tried += std::string(tried.empty() ? "" : "; ") + (e ? e : n);
+    }
+  };
+  if (!g_rccl.path.empty()) {
+    attempt(g_rccl.path.c_str(), RTLD_NOW | RTLD_LOCAL);
+  } else {
+    // an already-loaded librccl (e.g. the one a host framework ships) first, then the ROCm installation's
+    for (const char* n : {"librccl.so", "librccl.so.1"}) attempt(n, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) attempt(n, RTLD_NOW | RTLD_LOCAL);
+  }
   if (!h) {
-    *why = std::string("librccl not loadable: ") + (dlerror() ? dlerror() : "?");
+    *why = "librccl not loadable: " + (tried.empty() ? std::string("?") : tried);
     return false;
   }
   auto sym = [&](const char* n) { return dlsym(h, n); };
@@ -1087,28 +1107,72 @@ bool rccl_load(std::string* why) {
   g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
   g_rccl.Reduce = (decltype(g_rccl.Reduce))sym("ncclReduce");
   g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
-  if (!g_rccl.CommInitAll || !g_rccl.GroupStart || !g_rccl.GroupEnd || !g_rccl.Reduce || !g_rccl.GetErrorString) {
-    *why = "librccl lacks ncclCommInitAll / ncclGroupStart / ncclGroupEnd / ncclReduce";
+  if (!g_rccl.CommInitAll || !g_rccl.CommDestroy || !g_rccl.GroupStart || !g_rccl.GroupEnd || !g_rccl.Reduce || !g_rccl.GetErrorString) {
+    *why = "librccl lacks ncclCommInitAll / ncclCommDestroy / ncclGroupStart / ncclGroupEnd / ncclReduce / ncclGetErrorString";
+    dlclose(h);
     return false;
   }
   g_rccl.lib = h;
   return true;
 }
 
+// (g_rccl.mu held) destroy the cached cliques
+void rccl_drop_comms() {
+  if (g_rccl.CommDestroy)
+    for (auto& kv : g_rccl.comms)
+      for (ncclComm_t c : kv.second)
+        if (c) (void)g_rccl.CommDestroy(c);
+  g_rccl.comms.clear();
+}
+
+// ONE collective over the distinct devices: reduce(sum) of the float3 framebuffers heads[k]->d_frame (device devs[k],
+// stream heads[k]->own_stream) to heads[0]'s.  On any failure the group is still closed and the communicators of this
+// device list are dropped (their state is unknown); the caller synchronizes the streams.
+int rccl_reduce_frames(const std::vector<int>& devs, const std::vector<rtg_scene*>& heads, size_t n_floats) {
+  std::lock_guard<std::mutex> lock(g_rccl.mu);
+  std::string why;
+  if (!rccl_load(&why)) return fail(RTG_ERR_DEVICE, why);
+  auto it = g_rccl.comms.find(devs);
+  if (it == g_rccl.comms.end()) {
+    std::vector<ncclComm_t> c(devs.size(), nullptr);
+    ncclResult_t r = g_rccl.CommInitAll(c.data(), (int)devs.size(), devs.data());
+    if (r != ncclSuccess) return fail(RTG_ERR_DEVICE, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r));
+    it = g_rccl.comms.emplace(devs, std::move(c)).first;
+  }
+  std::string err;
+  ncclResult_t r = g_rccl.GroupStart();
+  if (r != ncclSuccess) {
+    err = std::string("ncclGroupStart: ") + g_rccl.GetErrorString(r);
+  } else {
+    for (size_t k = 0; k < devs.size() && err.empty(); k++) {
+      hipError_t he = hipSetDevice(devs[k]);
+      if (he != hipSuccess) {
+        err = std::string("hipSetDevice: ") + hipGetErrorString(he);
+        break;
+      }
+      r = g_rccl.Reduce(heads[k]->d_frame, heads[k]->d_frame, n_floats, ncclFloat, ncclSum, 0, it->second[k], heads[k]->own_stream);
+      if (r != ncclSuccess) err = std::string("ncclReduce: ") + g_rccl.GetErrorString(r);
+      else g_rccl.n_reduces++;
+    }
+    const ncclResult_t r2 = g_rccl.GroupEnd();  // always: a group left open would swallow every later RCCL call of the process
+    if (r2 != ncclSuccess && err.empty()) err = std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(r2);
+  }
+  if (!err.empty()) {
+    for (ncclComm_t c : it->second)
+      if (c) (void)g_rccl.CommDestroy(c);
+    g_rccl.comms.erase(it);
+    return fail(RTG_ERR_DEVICE, err);
+  }
+  return RTG_OK;
+}
+
 __global__ void add_frames_kernel(size_t n, float* __restrict__ dst, const float* __restrict__ src) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = dst[i] + src[i];  // every pixel has ONE non-zero contributor: x + 0 is exact
 }
-}  // namespace
 
-int rtg_par_cast_multi(rtg_scene* const* scenes, int n_scenes, const rtg_camera* camera, const rtg_params* params,
-                       float* out_rgb, rtg_stats* stats) {
-  if (!scenes || n_scenes <= 0 || !camera || !params || !out_rgb) return fail(RTG_ERR_INVALID, "null argument");
-  if (params->struct_size != sizeof(rtg_params)) return fail(RTG_ERR_INVALID, "rtg_params.struct_size mismatch");
-  if (params->nranks > 1u) return fail(RTG_ERR_INVALID, "rtg_par_cast_multi shards by itself: params.rank / nranks must be 0 / 0|1");
-  if (stats && stats->struct_size != sizeof(rtg_stats)) return fail(RTG_ERR_INVALID, "rtg_stats.struct_size mismatch");
-  for (int i = 0; i < n_scenes; i++)
-    if (!scenes[i]) return fail(RTG_ERR_INVALID, "null scene handle");
+int par_cast_multi_body(rtg_scene* const* scenes, int n_scenes, const rtg_camera* camera, const rtg_params* params, float* out_rgb,
+                        rtg_stats* stats) {
   const size_t n_floats = (size_t)params->nx * params->ny * 3;
   const size_t bytes = n_floats * sizeof(float);
   const bool count = stats && (params->flags & RTG_FLAG_COUNTERS);
@@ -1137,8 +1201,10 @@ int rtg_par_cast_multi(rtg_scene* const* scenes, int n_scenes, const rtg_camera*
   // (2) scenes that share a device with an earlier one are summed there; one frame per DISTINCT device remains
   std::vector<int> devs;          // distinct devices in order of first appearance
   std::vector<rtg_scene*> heads;  // the scene holding each device's partial frame
+  bool force_rccl = false;
   for (int i = 0; i < n_scenes; i++) {
     rtg_scene* s = scenes[i];
+    force_rccl = force_rccl || s->force_rccl != 0;
     size_t k = 0;
     while (k < devs.size() && devs[k] != s->device) k++;
     if (k == devs.size()) {
@@ -1151,26 +1217,12 @@ int rtg_par_cast_multi(rtg_scene* const* scenes, int n_scenes, const rtg_camera*
                        heads[k]->d_frame, s->d_frame);
     HIP_TRY(hipGetLastError());
   }
-  // (3) ONE collective over the distinct devices: reduce(sum) of the float3 framebuffer to the first device (xGMI)
-  if (devs.size() > 1) {
-    std::lock_guard<std::mutex> lock(g_rccl.mu);
-    std::string why;
-    if (!rccl_load(&why)) return fail(RTG_ERR_DEVICE, why);
-    auto it = g_rccl.comms.find(devs);
-    if (it == g_rccl.comms.end()) {
-      std::vector<ncclComm_t> c(devs.size());
-      ncclResult_t r = g_rccl.CommInitAll(c.data(), (int)devs.size(), devs.data());
-      if (r != ncclSuccess) return fail(RTG_ERR_DEVICE, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r));
-      it = g_rccl.comms.emplace(devs, std::move(c)).first;
-    }
-    ncclResult_t r = g_rccl.GroupStart();
-    for (size_t k = 0; k < devs.size() && r == ncclSuccess; k++) {
-      HIP_TRY(hipSetDevice(devs[k]));
-      r = g_rccl.Reduce(heads[k]->d_frame, heads[k]->d_frame, n_floats, ncclFloat, ncclSum, 0, it->second[k], heads[k]->own_stream);
-    }
-    ncclResult_t r2 = g_rccl.GroupEnd();
-    if (r == ncclSuccess) r = r2;
-    if (r != ncclSuccess) return fail(RTG_ERR_DEVICE, std::string("ncclReduce: ") + g_rccl.GetErrorString(r));
+  // (3) ONE collective over the distinct devices: reduce(sum) of the float3 framebuffer to the first device (xGMI).
+  // `force_rccl`: also with ONE distinct device (a clique of one) -- the same dlopen / ncclCommInitAll / grouped in-place
+  // ncclReduce code as on a node, which one-GPU test boxes could otherwise never execute.
+  if (devs.size() > 1 || force_rccl) {
+    int rc = rccl_reduce_frames(devs, heads, n_floats);
+    if (rc) return rc;
   }
   // (4) wait, copy the assembled frame out, gather stats (kernel time = the slowest shard)
   for (rtg_scene* h : heads) {
@@ -1201,6 +1253,46 @@ int rtg_par_cast_multi(rtg_scene* const* scenes, int n_scenes, const rtg_camera*
     }
     *stats = total;
   }
+  return RTG_OK;
+}
+}  // namespace
+
+int rtg_par_cast_multi(rtg_scene* const* scenes, int n_scenes, const rtg_camera* camera, const rtg_params* params,
+                       float* out_rgb, rtg_stats* stats) {
+  if (!scenes || n_scenes <= 0 || !camera || !params || !out_rgb) return fail(RTG_ERR_INVALID, "null argument");
+  if (params->struct_size != sizeof(rtg_params)) return fail(RTG_ERR_INVALID, "rtg_params.struct_size mismatch");
+  if (params->nranks > 1u) return fail(RTG_ERR_INVALID, "rtg_par_cast_multi shards by itself: params.rank / nranks must be 0 / 0|1");
+  if (stats && stats->struct_size != sizeof(rtg_stats)) return fail(RTG_ERR_INVALID, "rtg_stats.struct_size mismatch");
+  for (int i = 0; i < n_scenes; i++) {
+    if (!scenes[i]) return fail(RTG_ERR_INVALID, "null scene handle");
+    // one handle = one frame, one work queue, one stream: the same handle twice would wipe its own tiles
+    for (int k = 0; k < i; k++)
+      if (scenes[k] == scenes[i]) return fail(RTG_ERR_INVALID, "rtg_par_cast_multi: the same scene handle appears twice (one handle per shard)");
+  }
+  const int rc = par_cast_multi_body(scenes, n_scenes, camera, params, out_rgb, stats);
+  if (rc != RTG_OK) {
+    // whatever was queued before the failure must not outlive the call (the caller may free out_rgb, destroy the handles
+    // or call again): drain every stream that may hold work, keeping the first error message
+    const std::string first = g_err;
+    for (int i = 0; i < n_scenes; i++) {
+      if (!scenes[i]->own_stream) continue;
+      if (hipSetDevice(scenes[i]->device) == hipSuccess) (void)hipStreamSynchronize(scenes[i]->own_stream);
+    }
+    g_err = first;
+  }
+  return rc;
+}
+
+int rtg_multi_reset(const char* rccl_library_or_null, uint64_t* n_reduces_or_null) {
+  std::lock_guard<std::mutex> lock(g_rccl.mu);
+  if (n_reduces_or_null) *n_reduces_or_null = g_rccl.n_reduces;
+  g_rccl.n_reduces = 0;
+  rccl_drop_comms();
+  if (g_rccl.lib) dlclose(g_rccl.lib);
+  g_rccl.lib = nullptr;
+  g_rccl.CommInitAll = nullptr, g_rccl.CommDestroy = nullptr, g_rccl.GroupStart = nullptr, g_rccl.GroupEnd = nullptr;
+  g_rccl.Reduce = nullptr, g_rccl.GetErrorString = nullptr;
+  g_rccl.path = rccl_library_or_null ? rccl_library_or_null : "";
   return RTG_OK;
 }
 
@@ -1246,7 +1338,10 @@ int rtg_debug_samples(rtg_scene* s, const rtg_camera* camera, const rtg_params* 
     const uint32_t tiles = tiles_x * tiles_y;
     const uint64_t owned = tiles > d.rank ? (tiles - d.rank + d.nranks - 1) / d.nranks : 0;
     const uint64_t pix_work = owned * d.tile_w * d.tile_h;
-    const size_t table = (size_t)4 * d.ns * pix_work, slots = (size_t)s->num_cus * 16 * std::max(FPOOL, POOL) * 3;
+    // per-slot accumulators, indexed by (workgroup * waves + wave): a CU holds at most 32 waves of these kernels, and the
+    // `wg_per_cu` option may ask for more (queued) workgroups of up to 16 waves each
+    const size_t trace_waves = (size_t)s->num_cus * std::max(32, s->wg_per_cu > 0 ? s->wg_per_cu * 16 : 0);
+    const size_t table = (size_t)4 * d.ns * pix_work, slots = trace_waves * std::max(FPOOL, POOL) * 3;
     DevBuf<uint32_t> d_trace;
     HIP_TRY(d_trace.alloc(table + slots));
     HIP_TRY(hipMemset(d_trace.p, 0, (table + slots) * sizeof(uint32_t)));

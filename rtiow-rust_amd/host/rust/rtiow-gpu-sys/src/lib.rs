@@ -162,6 +162,9 @@ extern "C" {
         stats_or_null: *mut rtg_stats,
     ) -> c_int;
 
+    /// Drop the cached RCCL communicators, unload librccl, choose the library the next `rtg_par_cast_multi` loads.
+    pub fn rtg_multi_reset(rccl_library_or_null: *const c_char, n_reduces_or_null: *mut u64) -> c_int;
+
     // ---- output stage (print_ppm's quantisation, lib.rs:348-356)
     pub fn rtg_tonemap(device: c_int, n: usize, rgb: *const c_float, out_u8: *mut u8) -> c_int;
     pub fn rtg_tonemap_device(device: c_int, n: usize, d_rgb: *const c_float, d_out_u8: *mut u8, hip_stream: *mut c_void) -> c_int;

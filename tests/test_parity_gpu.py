@@ -186,6 +186,49 @@ def test_par_cast_multi_in_library_shard_and_reduce(pkg, gpu, oracle, name, nx, 
         gpu.par_cast_multi(scenes, cam_g, nx, ny, ns, rank=1, nranks=2)
 
 
+def test_par_cast_multi_through_the_real_rccl_symbols(pkg, gpu, oracle):
+    """The RCCL leg of rtg_par_cast_multi EXECUTED (round 2 had only ever run the same-device add): with the scene option
+    `force_rccl` the call goes dlopen(librccl) -> ncclCommInitAll -> ncclGroupStart / in-place ncclReduce(sum, root 0) /
+    ncclGroupEnd even when all handles sit on one device (a clique of one on this one-GPU box; with >= 2 GPUs visible the
+    handles are spread over two of them and the clique is a real one).  The frame must still be the oracle's, bit for bit;
+    rtg_multi_reset reports how many ncclReduce calls were issued, destroys the communicators and unloads the library.
+    A library that cannot be loaded is RTG_ERR_DEVICE with dlopen's reason -- not a crash (round 2: dlerror() called
+    twice -> std::string(NULL))."""
+    nx, ny, ns = 96, 64, 6
+    so, cam_o, _, _, _ = build_case(pkg, oracle, "book1", nx, ny)
+    ref, st_o = so.par_cast(cam_o, nx, ny, ns, stats=True)
+    n_dev = gpu.device_count()
+    gpu.multi_reset()
+    for n in (1, 2, 3):
+        scenes = []
+        for i in range(n):
+            b = gpu.builder()
+            world, cam_g, _ = pkg.scenes.random_scene(b, nx, ny)
+            sg = b.scene(world, device=i % min(n_dev, 2))
+            sg.set_option("force_rccl", 1)
+            scenes.append(sg)
+        img, st = gpu.par_cast_multi(scenes, cam_g, nx, ny, ns, stats=True)
+        assert_bit_equal(img, ref, "force_rccl, %d handles" % n)
+        for k in ("samples", "aabb_tests", "prim_tests", "shaded_hits", "rays", "draws"):
+            assert st[k] == st_o[k], (n, k)
+        assert_bit_equal(gpu.par_cast_multi(scenes, cam_g, nx, ny, ns), ref, "force_rccl, %d handles, second frame (cached clique)" % n)
+    issued = gpu.multi_reset()
+    # one ncclReduce per distinct device and frame: 3 handle counts x 2 frames x (1 device, or 2 once n >= 2)
+    assert issued == (6 if n_dev < 2 else 2 + 4 + 4), issued
+    # the same handle twice: refused (it would wipe its own tiles), nothing rendered
+    with pytest.raises(pkg.RtError) as ei:
+        gpu.par_cast_multi([scenes[0], scenes[0]], cam_g, nx, ny, ns)
+    assert ei.value.code == pkg.capi.ERR_INVALID and "twice" in str(ei.value)
+    # an unloadable library: a clean error with the loader's reason, and the next call with the default library works again
+    gpu.multi_reset("/nonexistent/librccl-missing.so")
+    with pytest.raises(pkg.RtError) as ei:
+        gpu.par_cast_multi(scenes, cam_g, nx, ny, ns)
+    assert ei.value.code == pkg.capi.ERR_DEVICE and "librccl" in str(ei.value) and "nonexistent" in str(ei.value)
+    assert gpu.multi_reset() == 0
+    assert_bit_equal(gpu.par_cast_multi(scenes, cam_g, nx, ny, ns), ref, "after the failed load")
+    assert gpu.multi_reset() == (1 if n_dev < 2 else 2)
+
+
 def test_ragged_image_sizes(pkg, gpu, oracle):
     """Sizes that are not multiples of the 16x16 block / 8x8 wave tile, and 1-pixel images."""
     for (nx, ny) in [(1, 1), (17, 9), (33, 47), (15, 64)]:
