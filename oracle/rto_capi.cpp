@@ -46,6 +46,7 @@ struct rto_builder {
   std::vector<MaterialPtr> materials;
   std::vector<ObjectPtr> objects;
   std::shared_ptr<PerlinTables> perlin;
+  Bvh::TieAudit ties;  // oracle-only: rto_builder_bvh_ties
 };
 struct rto_scene {
   World world;
@@ -258,12 +259,23 @@ rto_id rto_object_bvh(rto_builder* b, const rto_id* objects, size_t n, float e0,
     objs.push_back(o);
   }
   try {
-    std::shared_ptr<Bvh> bvh = Bvh::build(std::move(objs), Range{e0, e1});
+    std::shared_ptr<Bvh> bvh = Bvh::build(std::move(objs), Range{e0, e1}, &b->ties);
     return push_obj(b, bvh);
   } catch (const std::exception& e) {
     fail(n == 0 ? -2 : -3, e.what());
     return RTO_INVALID_ID;
   }
+}
+
+// ORACLE-ONLY (no product counterpart): the tie audit of Bvh::new's sort (rto_scene.hpp TieAudit).  `seed` != 0: every later
+// rto_object_bvh of this builder orders runs of equal sort keys at random (what bvh.rs:51's sort_unstable_by may do); 0 = the
+// documented stable rule.  out[4] (may be NULL) = {sorts, sorts with tied keys, tied keys, sorts whose tie straddles the
+// median split} accumulated over the builder's rto_object_bvh calls so far.
+int rto_builder_bvh_ties(rto_builder* b, uint64_t seed, uint64_t* out) {
+  if (!b) return fail(-1, "null argument");
+  if (out) out[0] = b->ties.sorts, out[1] = b->ties.sorts_with_ties, out[2] = b->ties.tied_keys, out[3] = b->ties.straddling;
+  b->ties.seed = seed;
+  return 0;
 }
 
 rto_id rto_object_bvh_sah(rto_builder* b, const rto_id* objects, size_t n, float e0, float e1) {

@@ -425,9 +425,24 @@ struct Bvh final : Object {
   std::unique_ptr<Bvh> left, right;  // BvhContents::Node
   ObjectPtr leaf;                    // BvhContents::Leaf
 
+  // Tie audit (tests/test_bvh_ties.py): what `sort_unstable_by` (bvh.rs:51) is free to do.  Counts the sorts whose keys
+  // tie and those where a run of equal keys STRADDLES the median split (only there can the tie order change which leaf
+  // goes left or right, i.e. the tree's shape); with seed != 0 every run of equal keys is shuffled after the stable sort
+  // -- any outcome an unstable sort could produce, at every level independently.
+  struct TieAudit {
+    uint64_t seed = 0;  // 0 = the documented rule: stable (ties keep input order)
+    uint64_t sorts = 0, sorts_with_ties = 0, tied_keys = 0, straddling = 0;
+    uint64_t next() {  // splitmix64
+      uint64_t z = (seed += 0x9e3779b97f4a7c15ull);
+      z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+      z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+      return z ^ (z >> 31);
+    }
+  };
+
   // bvh.rs:22-81.  `sort_unstable_by` tie order is rustc-version specific; this restatement uses a
   // STABLE sort (ties keep input order), which the build documents as its tie rule.
-  static std::unique_ptr<Bvh> build(std::vector<ObjectPtr> objs, Range exposure) {
+  static std::unique_ptr<Bvh> build(std::vector<ObjectPtr> objs, Range exposure, TieAudit* audit = nullptr) {
     if (objs.empty()) throw std::runtime_error("Can't create a BVH from zero objects.");  // bvh.rs:60
     auto axis_range = [&](int axis) {  // bvh.rs:27-35
       float start = F32_MAX, end = F32_MIN;
@@ -458,6 +473,24 @@ struct Bvh final : Object {
     }
     std::stable_sort(keyed.begin(), keyed.end(),
                      [](const auto& a, const auto& b) { return a.first < b.first; });
+    if (audit && keyed.size() > 1) {
+      audit->sorts++;
+      bool any = false;
+      for (size_t i = 0; i < keyed.size();) {
+        size_t j = i + 1;
+        while (j < keyed.size() && keyed[j].first == keyed[i].first) j++;
+        if (j - i > 1) {
+          any = true;
+          audit->tied_keys += j - i;
+          if (audit->seed != 0)  // Fisher-Yates inside the run of equal keys
+            for (size_t k = j - 1; k > i; k--) std::swap(keyed[k], keyed[i + audit->next() % (k - i + 1)]);
+        }
+        i = j;
+      }
+      const size_t h = keyed.size() / 2;
+      if (any) audit->sorts_with_ties++;
+      if (keyed[h - 1].first == keyed[h].first) audit->straddling++;
+    }
     auto node = std::make_unique<Bvh>();
     if (keyed.size() == 1) {  // bvh.rs:61-65
       node->bbox = keyed[0].second->bounding_box(exposure);
@@ -468,8 +501,8 @@ struct Bvh final : Object {
     size_t half = keyed.size() / 2;  // bvh.rs:68-72
     std::vector<ObjectPtr> l, r;
     for (size_t i = 0; i < keyed.size(); i++) (i < half ? l : r).push_back(keyed[i].second);
-    node->right = build(std::move(r), exposure);
-    node->left = build(std::move(l), exposure);
+    node->right = build(std::move(r), exposure, audit);
+    node->left = build(std::move(l), exposure, audit);
     node->bbox = node->left->bbox.merge(node->right->bbox);
     node->size = node->left->size + node->right->size;
     return node;

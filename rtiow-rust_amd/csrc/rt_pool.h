@@ -124,6 +124,12 @@ struct ChunkMode {
                          // 8 % of a C2 launch); written on the LAUNCH STREAM by write_lpt_descriptor, so launches stay ordered
   uint32_t lpt_samples;  // samples [0, lpt_samples) of every pixel belong to phase 1 (0 = off)
   uint32_t lpt_deep;     // a scatter event counts towards its block's cost from this bounce on
+  // Sample passes (bounded scratch): a launch renders the samples [s_begin, P.ns) of every pixel -- P.ns of the LAUNCH is
+  // the end of its pass, not the frame's sample count -- and `scratch` is biased so that sample s of pixel work index w
+  // still sits at scratch[3 * (s * pix_work + w)].  One pass (s_begin = 0, P.ns = ns) unless the frame's per-sample
+  // colours exceed the scratch budget (rtg_api.hip render_passes); the fold kernel carries the running per-pixel sum
+  // from pass to pass in the framebuffer itself, so the fold stays the reference's left fold (lib.rs:365-374).
+  uint32_t s_begin;
 };
 RT_DEV uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -244,19 +250,23 @@ __global__ void write_launch_consts(LaunchConsts* dst, LaunchConsts v) { *dst = 
 // stream-ordered update of the descriptor (a kernel argument by value: no host buffer has to outlive the call)
 __global__ void write_lpt_descriptor(LptQueue* dst, LptQueue v) { *dst = v; }
 
-// second pass of the chunk mode: ordered fold of the per-sample colours (vec3.rs:195-203, lib.rs:374)
-__global__ void fold_samples_kernel(DevParams P, ChunkMode cm, float* __restrict__ out) {
+// second pass of the chunk mode: ordered fold of the per-sample colours (vec3.rs:195-203, lib.rs:374).  Samples
+// [cm.s_begin, P.ns) of this pass are added IN ORDER to the running sum of the earlier passes -- (0, 0, 0) for the first
+// pass (vec3.rs:197), else what the previous pass left in the framebuffer, the same f32 bits the sequential fold would hold
+// at that point -- and the last pass divides by the frame's sample count `ns_frame` (lib.rs:374).
+__global__ void fold_samples_kernel(DevParams P, ChunkMode cm, float* __restrict__ out, uint32_t ns_frame) {
   uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= cm.pix_work) return;
   uint32_t x, row;
   if (!work_to_pixel(P, w, x, row)) return;
+  float* o = out + 3ull * ((size_t)row * P.nx + x);
   V3 col = mk(0.f, 0.f, 0.f);
-  for (uint32_t s = 0; s < P.ns; s++) {
+  if (cm.s_begin != 0u) col = mk(o[0], o[1], o[2]);
+  for (uint32_t s = cm.s_begin; s < P.ns; s++) {
     const float* c = cm.scratch + 3ull * ((size_t)s * cm.pix_work + w);
     col = vadd(col, mk(RT_SCRATCH_LOAD(c), RT_SCRATCH_LOAD(c + 1), RT_SCRATCH_LOAD(c + 2)));
   }
-  col = sdiv(col, (float)P.ns);
-  float* o = out + 3ull * ((size_t)row * P.nx + x);
+  if (P.ns == ns_frame) col = sdiv(col, (float)ns_frame);
   o[0] = col.x, o[1] = col.y, o[2] = col.z;
 }
 
@@ -801,7 +811,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
               uint32_t w = w_next + r, first = 0;
               if (cm.scratch) {  // work item = (chunk, pixel), pixel-minor so a wave's grab stays coherent
                 w += w_delta;
-                first = w_chunk * cm.chunk;
+                first = cm.s_begin + w_chunk * cm.chunk;
               }
               if (work_to_pixel(P, w, x, row) && first < P.ns) {
                 s = first;

@@ -19,8 +19,8 @@
 //  * a medium draws from the event's RNG stream by index (event_draw), and the number of draws made
 //    during traversal travels with the path so that Material::scatter continues the stream where
 //    traversal left it (draw order of SURVEY 8a);
-//  * always one sample per work item + ordered fold (the host falls back to render_kernel when the
-//    sample scratch would not fit).
+//  * always one sample per work item + ordered fold (frames whose sample colours exceed the scratch budget are rendered
+//    in several sample passes: rtg_api.hip samples_per_pass).
 #pragma once
 #include "rt_pool.h"
 
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
             if (r < avail) {
               uint32_t w = w_next + r;
               w += w_delta;
-              const uint32_t first = w_chunk * cm.chunk;
+              const uint32_t first = cm.s_begin + w_chunk * cm.chunk;
               if (work_to_pixel(P, w, x, row) && first < P.ns) {
                 s = first;
                 st = ST_GEN;

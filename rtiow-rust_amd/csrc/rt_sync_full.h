@@ -194,7 +194,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           const uint32_t r = lane_rank(need);
           if (r < avail) {
             const uint32_t w = w_next + r + w_delta;
-            const uint32_t first = w_chunk * cm.chunk;
+            const uint32_t first = cm.s_begin + w_chunk * cm.chunk;
             if (work_to_pixel(P, w, px, prow) && first < P.ns) {
               ps = first;
               st = ST_GEN;

@@ -172,6 +172,8 @@ struct rtg_scene {
   float* d_scratch = nullptr;  // chunk-mode per-sample colours
   size_t scratch_bytes = 0;
   int force_chunks = 0;        // RTG_CHUNKS: 0 = automatic
+  uint64_t scratch_limit = 0;  // option scratch_mb: budget of the per-sample colour scratch in bytes, 0 = half of the free HBM
+  bool whole_scratch = false;  // the kernel trace reads every sample colour back: one pass regardless of the budget
   LaunchConsts* d_consts = nullptr;  // camera / frame parameters / chunk description of the launch (rt_pool.h), written on the launch stream
   uint32_t* d_lpt = nullptr;   // cost-ordered work queue (rt_pool.h LptQueue)
   size_t lpt_bytes = 0;
@@ -207,7 +209,32 @@ static uint64_t scratch_cap() {
   return (uint64_t)free_b / 2;
 }
 
+// Sample passes.  The pool kernels park every sample colour in a [sample][pixel work index] scratch (12 B each) that the
+// ordered fold consumes; a frame whose scratch would exceed the budget (option scratch_mb, default half of the free HBM)
+// or whose work items would overflow the 32-bit queue counter is rendered in several passes over consecutive sample
+// ranges, the fold kernel carrying the running per-pixel sum from pass to pass (rt_pool.h ChunkMode::s_begin) -- the
+// same left fold, bit for bit, with O(budget) instead of O(spp) memory.  Returns the samples per pass (>= 1).
+static uint32_t samples_per_pass(const rtg_scene* s, uint64_t pix_work, uint32_t ns) {
+  const uint64_t per_sample = pix_work * 3 * sizeof(float);
+  uint64_t budget = s->scratch_limit ? s->scratch_limit : std::max<uint64_t>(scratch_cap(), s->scratch_bytes);
+  if (s->whole_scratch) budget = ~0ull;
+  uint64_t k = std::max<uint64_t>(1, budget / std::max<uint64_t>(per_sample, 1));
+  k = std::min<uint64_t>(k, 0xfffffffeull / std::max<uint64_t>(pix_work, 1));  // work items of a pass: one 32-bit counter
+  k = std::max<uint64_t>(1, std::min<uint64_t>(k, ns));
+  const uint64_t n_pass = (ns + k - 1) / k;
+  return (uint32_t)((ns + n_pass - 1) / n_pass);  // balanced passes
+}
+
 static uint64_t owned_pixels(const DevParams& d);
+static hipError_t grow(void** buf, size_t* have, size_t need) {
+  if (need <= *have) return hipSuccess;
+  if (*buf) (void)hipFree(*buf);
+  *buf = nullptr, *have = 0;
+  hipError_t e = hipMalloc(buf, need);
+  if (e == hipSuccess) *have = need;
+  return e;
+}
+
 static hipError_t setup_lpt(rtg_scene* s, ChunkMode& cm, uint64_t capacity, hipStream_t stream);
 
 // Lean scenes, ray-pool kernel (rt_pool.h): one persistent 1024-thread workgroup per CU.
@@ -219,38 +246,26 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
   uint32_t owned = tiles > d.rank ? (tiles - d.rank + d.nranks - 1) / d.nranks : 0;
   const uint64_t pix_work = (uint64_t)owned * d.tile_w * d.tile_h;
   if (pix_work == 0) return hipSuccess;  // this rank owns no tile
+  if (pix_work > 0xfffffffeull) return hipErrorInvalidValue;
   const int bt = s->pool_threads;
   const uint32_t waves = (uint32_t)bt / 64;
-  // sample-chunk mode (see rt_pool.h)
-  ChunkMode cm{};
-  cm.scratch = nullptr, cm.chunk = d.ns, cm.n_chunks = 1, cm.pix_work = (uint32_t)pix_work;
-  {
-    // Default: one sample per work item.  Work items are then ~100x more numerous than path slots, so
-    // the end-of-frame tail (slots finishing their last item while the queue is empty) is negligible;
-    // measured on C2: 40.6 ms with one pixel (50 samples) per item, 23.5 ms with one sample per item.
-    uint64_t n_chunks = d.ns;
-    if (s->force_chunks > 0) n_chunks = (uint64_t)s->force_chunks;
-    if (n_chunks > d.ns) n_chunks = d.ns;
-    const uint64_t need = pix_work * d.ns * 3 * sizeof(float);
-    if (n_chunks > 1 && pix_work * n_chunks <= 0xfffffffeull && (need <= s->scratch_bytes || need <= scratch_cap())) {
-      if (need > s->scratch_bytes) {
-        if (s->d_scratch) (void)hipFree(s->d_scratch);
-        s->d_scratch = nullptr, s->scratch_bytes = 0;
-        hipError_t ea = hipMalloc((void**)&s->d_scratch, need);
-        if (ea != hipSuccess) return ea;
-        s->scratch_bytes = need;
-      }
-      cm.chunk = (uint32_t)((d.ns + n_chunks - 1) / n_chunks);
-      cm.n_chunks = (uint32_t)((d.ns + cm.chunk - 1) / cm.chunk);
-      cm.scratch = s->d_scratch;
-    }
+  // Sample-chunk mode (see rt_pool.h).  Default: one sample per work item.  Work items are then ~100x more numerous than
+  // path slots, so the end-of-frame tail (slots finishing their last item while the queue is empty) is negligible;
+  // measured on C2: 40.6 ms with one pixel (50 samples) per item, 23.5 ms with one sample per item.
+  uint64_t n_chunks = d.ns;
+  if (s->force_chunks > 0) n_chunks = (uint64_t)s->force_chunks;
+  if (n_chunks > d.ns) n_chunks = d.ns;
+  const bool use_scratch = n_chunks > 1;  // else (ns = 1, or option chunks = 1): a slot folds its pixel's samples itself
+  uint32_t per_pass = d.ns, chunk = d.ns;
+  if (use_scratch) {
+    per_pass = samples_per_pass(s, pix_work, d.ns);
+    chunk = (uint32_t)((d.ns + n_chunks - 1) / n_chunks);
+    if (per_pass < d.ns) chunk = 1u;  // several passes: one sample per work item
+    hipError_t ea = grow((void**)&s->d_scratch, &s->scratch_bytes, pix_work * per_pass * 3 * sizeof(float));
+    if (ea != hipSuccess) return ea;
   }
-  s->last_pix_work = cm.scratch ? (uint32_t)pix_work : 0u;
-  uint64_t total_work = pix_work * cm.n_chunks;
-  if (total_work > 0xfffffffeull) return hipErrorInvalidValue;
+  s->last_pix_work = use_scratch && per_pass == d.ns ? (uint32_t)pix_work : 0u;
   uint32_t* queue = (uint32_t*)(s->d_counters + 7);
-  hipError_t e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream);  // re-initialise every call
-  if (e != hipSuccess) return e;
   const size_t lds_limit = 160 * 1024;
   const bool wide = s->bvh4 && s->wide_bytes != 0;
   const uint32_t image = wide ? s->wide_bytes : s->dev.lds_image_bytes;
@@ -264,7 +279,7 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
   if (wide) kernel = ray_lds ? render_lean_pool<true, COUNT, true, true> : render_lean_pool<true, COUNT, false, true>;
   else if (ray_lds) kernel = use_lds ? render_lean_pool<true, COUNT, true> : render_lean_pool<false, COUNT, true>;
   else kernel = use_lds ? render_lean_pool<true, COUNT, false> : render_lean_pool<false, COUNT, false>;
-  e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   int per_cu = s->wg_per_cu;
   if (per_cu <= 0) {
@@ -272,34 +287,42 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
     if (e != hipSuccess) return e;
   }
   if (per_cu < 1) per_cu = 1;
-  // a wave keeps POOL paths in flight; do not launch more waves than there is work for
-  uint64_t want = (total_work + (uint64_t)waves * POOL - 1) / ((uint64_t)waves * POOL);
-  uint32_t grid = (uint32_t)std::min<uint64_t>(want ? want : 1, (uint64_t)s->num_cus * per_cu);
-  e = setup_lpt(s, cm, (uint64_t)grid * waves * POOL, stream);
-  if (e != hipSuccess) return e;
-  if (s->verbose)
-    fprintf(stderr, "[rtg] pool: grid %u x %d threads, %d WG/CU, lds %zu B (program staged: %d, hot slot fields in LDS: %d), %u chunk(s) of %u samples, cost-ordered queue after %u chunk(s)\n", grid,
-            bt, per_cu, lds, (int)use_lds, (int)ray_lds, cm.n_chunks, cm.chunk, cm.lpt_samples / (cm.chunk ? cm.chunk : 1u));
-  {
-    size_t need = (size_t)grid * waves * POOL * POOL_FIELDS * sizeof(uint32_t);
-    if (need > s->slots_bytes) {
-      if (s->d_slots) (void)hipFree(s->d_slots);
-      s->d_slots = nullptr, s->slots_bytes = 0;
-      e = hipMalloc((void**)&s->d_slots, need);
+  for (uint32_t s0 = 0; s0 < d.ns; s0 += per_pass) {  // ONE pass unless the scratch budget is smaller than the frame's sample colours
+    DevParams dp = d;
+    dp.ns = std::min(d.ns, s0 + per_pass);  // the pass renders samples [s0, dp.ns)
+    ChunkMode cm{};
+    cm.scratch = nullptr, cm.chunk = d.ns, cm.n_chunks = 1, cm.pix_work = (uint32_t)pix_work, cm.s_begin = s0;
+    if (use_scratch) {
+      cm.chunk = chunk;
+      cm.n_chunks = (dp.ns - s0 + chunk - 1) / chunk;
+      cm.scratch = s->d_scratch - 3ull * s0 * pix_work;  // biased: sample s of work index w at scratch[3 * (s * pix_work + w)]
+    }
+    const uint64_t total_work = pix_work * cm.n_chunks;
+    if (total_work > 0xfffffffeull) return hipErrorInvalidValue;
+    e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream);  // re-initialise every pass
+    if (e != hipSuccess) return e;
+    // a wave keeps POOL paths in flight; do not launch more waves than there is work for
+    uint64_t want = (total_work + (uint64_t)waves * POOL - 1) / ((uint64_t)waves * POOL);
+    uint32_t grid = (uint32_t)std::min<uint64_t>(want ? want : 1, (uint64_t)s->num_cus * per_cu);
+    e = setup_lpt(s, cm, (uint64_t)grid * waves * POOL, stream);
+    if (e != hipSuccess) return e;
+    if (s->verbose)
+      fprintf(stderr, "[rtg] pool: samples [%u, %u) of %u: grid %u x %d threads, %d WG/CU, lds %zu B (program staged: %d, hot slot fields in LDS: %d), %u chunk(s) of %u samples, cost-ordered queue after %u chunk(s)\n",
+              s0, dp.ns, d.ns, grid, bt, per_cu, lds, (int)use_lds, (int)ray_lds, cm.n_chunks, cm.chunk, (cm.lpt_samples - (cm.lpt_samples ? s0 : 0u)) / (cm.chunk ? cm.chunk : 1u));
+    e = grow((void**)&s->d_slots, &s->slots_bytes, (size_t)grid * waves * POOL * POOL_FIELDS * sizeof(uint32_t));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(write_launch_consts, dim3(1), dim3(1), 0, stream, s->d_consts, LaunchConsts{cam, dp, cm});
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(bt), lds, stream, dev, (const LaunchConsts*)s->d_consts, d_out, (uint32_t)total_work, queue,
+                       s->d_counters, s->pool_tune, s->d_slots);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (cm.scratch) {
+      hipLaunchKernelGGL(fold_samples_kernel, dim3((uint32_t)((pix_work + 255) / 256)), dim3(256), 0, stream, dp, cm, d_out, d.ns);
+      e = hipGetLastError();
       if (e != hipSuccess) return e;
-      s->slots_bytes = need;
     }
   }
-  hipLaunchKernelGGL(write_launch_consts, dim3(1), dim3(1), 0, stream, s->d_consts, LaunchConsts{cam, d, cm});
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(bt), lds, stream, dev, (const LaunchConsts*)s->d_consts, d_out, (uint32_t)total_work, queue,
-                     s->d_counters, s->pool_tune, s->d_slots);
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  if (cm.scratch) {
-    hipLaunchKernelGGL(fold_samples_kernel, dim3((uint32_t)((pix_work + 255) / 256)), dim3(256), 0, stream, d, cm, d_out);
-    e = hipGetLastError();
-  }
-  return e;
+  return hipSuccess;
 }
 
 // The 4-wide image of a lean program that is ONE Bvh over spheres (rt_pool.h WIDE; option `bvh4`): every node record holds
@@ -371,15 +394,6 @@ static bool build_wide_image(const Packet* lo, const Packet* hi, size_t n, std::
   return ok && out.size() * 4u < 512u * 1024u;
 }
 
-static hipError_t grow(void** buf, size_t* have, size_t need) {
-  if (need <= *have) return hipSuccess;
-  if (*buf) (void)hipFree(*buf);
-  *buf = nullptr, *have = 0;
-  hipError_t e = hipMalloc(buf, need);
-  if (e == hipSuccess) *have = need;
-  return e;
-}
-
 // Cost-ordered work queue (rt_pool.h, ChunkMode): enabled when the frame has enough chunks for a measuring
 // phase and enough blocks to order; the buffers are re-zeroed on the launch stream every call.
 static hipError_t setup_lpt(rtg_scene* s, ChunkMode& cm, uint64_t capacity, hipStream_t stream) {
@@ -411,13 +425,13 @@ static hipError_t setup_lpt(rtg_scene* s, ChunkMode& cm, uint64_t capacity, hipS
   e = hipMemsetAsync(q.cost, 0, ((size_t)n_blocks + LPT_CTL) * sizeof(uint32_t), stream);
   if (e != hipSuccess) return e;
   cm.lpt = reinterpret_cast<const LptQueue*>(s->d_lpt);
-  cm.lpt_samples = phase1 * cm.chunk;
+  cm.lpt_samples = cm.s_begin + phase1 * cm.chunk;  // samples [s_begin, lpt_samples) of every pixel: phase 1 of this pass
   cm.lpt_deep = (uint32_t)s->lpt_deep;
   return hipSuccess;
 }
 
-// Full-feature scenes, ray-pool kernel (rt_pool_full.h).  Returns hipErrorNotSupported when the sample
-// scratch would not fit: the caller then uses the baseline kernel.
+// Full-feature scenes, ray-pool kernel (rt_pool_full.h) or, for list worlds without a Bvh, the lock-step kernel
+// (rt_sync_full.h): always one sample per work item + ordered fold, in as many sample passes as the scratch budget asks for.
 template <bool COUNT>
 static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const DevParams& d, float* d_out,
                                    hipStream_t stream) {
@@ -425,23 +439,18 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
   uint32_t tiles = tiles_x * tiles_y;
   uint32_t owned = tiles > d.rank ? (tiles - d.rank + d.nranks - 1) / d.nranks : 0;
   const uint64_t pix_work = (uint64_t)owned * d.tile_w * d.tile_h;
-  const uint64_t scratch_need = pix_work * d.ns * 3 * sizeof(float);
-  const uint64_t total_work = pix_work * d.ns;
-  if (total_work > 0xfffffffeull || (scratch_need > s->scratch_bytes && scratch_need > scratch_cap())) return hipErrorNotSupported;
   if (pix_work == 0) return hipSuccess;
+  if (pix_work > 0xfffffffeull) return hipErrorInvalidValue;
+  const uint32_t per_pass = samples_per_pass(s, pix_work, d.ns);
   const bool tex = (s->features & FEAT_TEXTURE) != 0;
   // ONE 16-wave workgroup per CU shares one LDS copy of the program (128 VGPRs per lane).
   const int bt_max = tex ? RT_FULL_TEX_THREADS : 1024;
   const int bt = s->full_threads > 0 && s->full_threads <= bt_max ? s->full_threads : bt_max;
   const uint32_t waves = (uint32_t)bt / 64;
-  hipError_t e = grow((void**)&s->d_scratch, &s->scratch_bytes, scratch_need);
+  hipError_t e = grow((void**)&s->d_scratch, &s->scratch_bytes, pix_work * per_pass * 3 * sizeof(float));
   if (e != hipSuccess) return e;
-  ChunkMode cm{};
-  cm.scratch = s->d_scratch, cm.chunk = 1u, cm.n_chunks = d.ns, cm.pix_work = (uint32_t)pix_work;
-  s->last_pix_work = (uint32_t)pix_work;
+  s->last_pix_work = per_pass == d.ns ? (uint32_t)pix_work : 0u;
   uint32_t* queue = (uint32_t*)(s->d_counters + 7);
-  e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream);
-  if (e != hipSuccess) return e;
   // Program placement: the whole program in LDS when it fits, else a leading window
   // (depth-first order: the window holds whole leading subtrees) and global memory for the rest.
   const size_t list_bytes = full_pool_lds_bytes(0, waves);
@@ -472,34 +481,49 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
     if (e != hipSuccess) return e;
   }
   if (per_cu < 1) per_cu = 1;
-  uint64_t want = (total_work + (uint64_t)waves * FPOOL - 1) / ((uint64_t)waves * FPOOL);
-  uint32_t grid = (uint32_t)std::min<uint64_t>(want ? want : 1, (uint64_t)s->num_cus * per_cu);
-  e = setup_lpt(s, cm, (uint64_t)grid * waves * FPOOL, stream);
-  if (e != hipSuccess) return e;
-  e = grow((void**)&s->d_slots, &s->slots_bytes, (size_t)grid * waves * FPOOL * FPOOL_FIELDS * sizeof(uint32_t));
-  if (e != hipSuccess) return e;
-  e = grow((void**)&s->d_stack, &s->stack_bytes, (size_t)grid * waves * (genb ? 2 : 1) * MAX_XFORM_DEPTH * 6 * 64 * sizeof(float));
-  if (e != hipSuccess) return e;
-  if (s->verbose)
-    fprintf(stderr, "[rtg] full pool: grid %u x %d threads, %d WG/CU, lds %zu B (program window: %u of %u records), cost-ordered queue after %u chunk(s)\n",
-            grid, bt, per_cu, lds, window, s->n_prog, cm.lpt_samples);
-  hipLaunchKernelGGL(write_launch_consts, dim3(1), dim3(1), 0, stream, s->d_consts, LaunchConsts{cam, d, cm});
-  if ((s->sync_full > 0 || (s->sync_full < 0 && s->n_box == 0)) && prog == 1) {  // list world without a Bvh: one path per lane, lock-step (rt_sync_full.h)
-    void (*k2)(DevScene, const LaunchConsts*, float*, uint32_t, uint32_t*, unsigned long long*, PoolTuning, float*, uint32_t);
+  const bool lock_step = (s->sync_full > 0 || (s->sync_full < 0 && s->n_box == 0)) && prog == 1;  // list world without a Bvh: one path per lane (rt_sync_full.h)
+  void (*k2)(DevScene, const LaunchConsts*, float*, uint32_t, uint32_t*, unsigned long long*, PoolTuning, float*, uint32_t) = nullptr;
+  const size_t lds2 = (size_t)window * 32;
+  if (lock_step) {
     if (genb) k2 = tex ? render_full_sync<1, true, COUNT, true> : render_full_sync<1, false, COUNT, true>;
     else k2 = tex ? render_full_sync<1, true, COUNT, false> : render_full_sync<1, false, COUNT, false>;
-    const size_t lds2 = (size_t)window * 32;
     e = hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k2, dim3(grid), dim3(bt), lds2, stream, s->dev, (const LaunchConsts*)s->d_consts, d_out, (uint32_t)total_work, queue,
-                       s->d_counters, s->sync_tune, s->d_stack, window);
-  } else
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(bt), lds, stream, s->dev, (const LaunchConsts*)s->d_consts, d_out, (uint32_t)total_work, queue,
-                     s->d_counters, s->full_tune, s->d_slots, s->d_stack, window);
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(fold_samples_kernel, dim3((uint32_t)((pix_work + 255) / 256)), dim3(256), 0, stream, d, cm, d_out);
-  return hipGetLastError();
+  }
+  for (uint32_t s0 = 0; s0 < d.ns; s0 += per_pass) {  // ONE pass unless the scratch budget is smaller than the frame's sample colours
+    DevParams dp = d;
+    dp.ns = std::min(d.ns, s0 + per_pass);
+    ChunkMode cm{};
+    cm.scratch = s->d_scratch - 3ull * s0 * pix_work, cm.chunk = 1u, cm.n_chunks = dp.ns - s0, cm.pix_work = (uint32_t)pix_work, cm.s_begin = s0;
+    const uint64_t total_work = pix_work * cm.n_chunks;
+    if (total_work > 0xfffffffeull) return hipErrorInvalidValue;
+    e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    uint64_t want = (total_work + (uint64_t)waves * FPOOL - 1) / ((uint64_t)waves * FPOOL);
+    uint32_t grid = (uint32_t)std::min<uint64_t>(want ? want : 1, (uint64_t)s->num_cus * per_cu);
+    e = setup_lpt(s, cm, (uint64_t)grid * waves * FPOOL, stream);
+    if (e != hipSuccess) return e;
+    e = grow((void**)&s->d_slots, &s->slots_bytes, (size_t)grid * waves * FPOOL * FPOOL_FIELDS * sizeof(uint32_t));
+    if (e != hipSuccess) return e;
+    e = grow((void**)&s->d_stack, &s->stack_bytes, (size_t)grid * waves * (genb ? 2 : 1) * MAX_XFORM_DEPTH * 6 * 64 * sizeof(float));
+    if (e != hipSuccess) return e;
+    if (s->verbose)
+      fprintf(stderr, "[rtg] full pool: samples [%u, %u) of %u: grid %u x %d threads, %d WG/CU, lds %zu B (program window: %u of %u records), cost-ordered queue after %u chunk(s)\n",
+              s0, dp.ns, d.ns, grid, bt, per_cu, lds, window, s->n_prog, cm.lpt_samples - (cm.lpt_samples ? s0 : 0u));
+    hipLaunchKernelGGL(write_launch_consts, dim3(1), dim3(1), 0, stream, s->d_consts, LaunchConsts{cam, dp, cm});
+    if (lock_step)
+      hipLaunchKernelGGL(k2, dim3(grid), dim3(bt), lds2, stream, s->dev, (const LaunchConsts*)s->d_consts, d_out, (uint32_t)total_work, queue,
+                         s->d_counters, s->sync_tune, s->d_stack, window);
+    else
+      hipLaunchKernelGGL(kernel, dim3(grid), dim3(bt), lds, stream, s->dev, (const LaunchConsts*)s->d_consts, d_out, (uint32_t)total_work, queue,
+                         s->d_counters, s->full_tune, s->d_slots, s->d_stack, window);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fold_samples_kernel, dim3((uint32_t)((pix_work + 255) / 256)), dim3(256), 0, stream, dp, cm, d_out, d.ns);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 template <bool COUNT>
@@ -512,11 +536,8 @@ static hipError_t launch_render(rtg_scene* s, const DevCamera& cam, const DevPar
   const bool pool_ok = accum_zero && s->kernel_version >= 3 && d.nx <= 0xffffu && d.ny <= 0xffffu;
   s->last_kernel = 1;
   if (geom != 0 && pool_ok) {
-    hipError_t e = launch_full_pool<COUNT>(s, cam, d, d_out, stream);
-    if (e != hipErrorNotSupported) {
-      s->last_kernel = 4;
-      return e;
-    }
+    s->last_kernel = 4;
+    return launch_full_pool<COUNT>(s, cam, d, d_out, stream);
   }
   if (geom == 0 && pool_ok) {
     s->last_kernel = 3;
@@ -885,6 +906,7 @@ int rtg_scene_set_option(rtg_scene* s, const char* name, int value) {
   const uint32_t u = (uint32_t)value;
   if (k == "kernel") s->kernel_version = value;                 // 3 = ray pools (default), 1 = one lane per pixel
   else if (k == "chunks") s->force_chunks = value;              // lean pool kernel: sample chunks per pixel, 0 = one sample per work item
+  else if (k == "scratch_mb") s->scratch_limit = value > 0 ? (uint64_t)value << 20 : 0;  // budget of the per-sample colour scratch (0 = half of the free HBM): larger frames render in sample passes
   else if (k == "lpt") s->lpt = value;                          // cost-ordered queue: 0 off, 1 block-major, 2 class-major (default)
   else if (k == "lpt_phase1") s->lpt_phase1 = value;
   else if (k == "lpt_deep") s->lpt_deep = value;
@@ -1350,7 +1372,9 @@ int rtg_debug_samples(rtg_scene* s, const rtg_camera* camera, const rtg_params* 
     const unsigned long long ptrs[2] = {(unsigned long long)(uintptr_t)d_trace.p, (unsigned long long)(uintptr_t)(d_trace.p + table)};
     HIP_TRY(hipMemcpy(s->d_counters + 30, ptrs, sizeof(ptrs), hipMemcpyHostToDevice));
     const DevCamera cam = to_dev(camera);
+    s->whole_scratch = true;  // the trace reads every sample colour back: one sample pass
     hipError_t e = launch_render<true>(s, cam, d, s->d_frame, nullptr);
+    s->whole_scratch = false;
     if (e == hipSuccess) e = hipDeviceSynchronize();
     (void)hipMemset(s->d_counters + 30, 0, 2 * sizeof(unsigned long long));
     if (e != hipSuccess) return hip_fail(e, "trace launch");

@@ -229,6 +229,40 @@ def test_par_cast_multi_through_the_real_rccl_symbols(pkg, gpu, oracle):
     assert gpu.multi_reset() == (1 if n_dev < 2 else 2)
 
 
+@pytest.mark.parametrize("name,nx,ny,ns,mb", [("cornell", 300, 300, 400, 16), ("book1", 300, 300, 400, 16), ("book2", 160, 160, 60, 1),
+                                               ("book1", 200, 120, 37, 1)])
+def test_bounded_sample_scratch_renders_in_passes(pkg, gpu, oracle, name, nx, ny, ns, mb, capfd):
+    """The per-sample colour scratch is O(budget), not O(spp): with a budget (option scratch_mb) smaller than the frame's
+    sample colours the frame is rendered in sample passes and the fold kernel carries the running per-pixel sum from pass
+    to pass -- still the reference's left fold (lib.rs:365-374): bit-exact against the oracle, counters included, on all
+    three pool kernels (lock-step / lean / full-feature), also sharded.  (Round 2 sent such frames to the 10x slower
+    baseline kernel.)"""
+    sg, cam_g, _, _, _ = build_case(pkg, gpu, name, nx, ny)
+    so, cam_o, _, _, _ = build_case(pkg, oracle, name, nx, ny)
+    ref, st_o = so.par_cast(cam_o, nx, ny, ns, stats=True)
+    sg.set_option("scratch_mb", mb)
+    sg.set_option("verbose", 1)
+    img, st = sg.par_cast(cam_g, nx, ny, ns, stats=True)
+    err = capfd.readouterr().err
+    n_pass = len([l for l in err.splitlines() if "pool: samples [" in l])
+    per_sample = ((nx + 15) // 16) * ((ny + 15) // 16) * 256 * 12
+    assert n_pass >= 2 and n_pass == -(-ns // -(-ns // -(-ns // max(1, (mb << 20) // per_sample)))), (n_pass, err[-400:])
+    assert "baseline" not in err
+    sg.set_option("verbose", 0)
+    assert_bit_equal(img, ref, "%s in %d passes" % (name, n_pass))
+    for k in ("samples", "aabb_tests", "prim_tests", "shaded_hits", "rays", "draws"):
+        assert st[k] == st_o[k], (name, k, st[k], st_o[k])
+    assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns), ref, name + " (timed variant)")
+    # a shard of the frame in passes, into a caller-owned canvas
+    canvas = np.zeros_like(ref)
+    for r in range(3):
+        canvas = sg.par_cast(cam_g, nx, ny, ns, rank=r, nranks=3, out=canvas)
+    assert_bit_equal(canvas, ref, name + " 3 shards in passes")
+    # back to one pass on the same handle
+    sg.set_option("scratch_mb", 0)
+    assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns), ref, name + " (one pass again)")
+
+
 def test_ragged_image_sizes(pkg, gpu, oracle):
     """Sizes that are not multiples of the 16x16 block / 8x8 wave tile, and 1-pixel images."""
     for (nx, ny) in [(1, 1), (17, 9), (33, 47), (15, 64)]:
