@@ -257,8 +257,15 @@ def main():
         rank_samples = px_rank * spp
         pmc, pmc_path = rl.find_profile(ROOT, (args.workload if args.bvh == "reference" else args.workload + "_" + args.bvh) + ("_bvh4" if args.bvh4 else ""))
         if pmc is not None:
-            roof = rl.valu_roofline(pmc, kernel_s, samples=rank_samples)
+            # counters are only quoted for the build and schedule they were collected on (profiles carry the git blob hashes
+            # of csrc/*): another build -> achieved / frac = null + the reason
+            knobs = sorted(k for k in os.environ if k.startswith("RTG_") and k != "RTG_BENCH_BACKEND" and os.environ[k] != pmc.get("env_options", {}).get(k))
+            stale = rl.profile_staleness(pmc, ROOT, lib_override=os.environ.get("RTIOW_GPU_LIB"), knobs=knobs)
+            if stale is None and (nx, ny) != (wnx, wny):
+                stale = "frame geometry %dx%d differs from the profiled %dx%d" % (nx, ny, wnx, wny)
+            roof = rl.valu_roofline(pmc, kernel_s, samples=rank_samples, stale=stale)
             roof["pmc_source"] = pmc_path
+            roof["pmc_build"] = pmc.get("build", {}).get("digest")
         else:   # no counter profile for this workload: the contract's keys with the unmeasured ones null
             roof = {"bound": "valu", "achieved": None, "peak": rl.N_CUS * rl.SIMDS_PER_CU * rl.NOMINAL_CLOCK_HZ / rl.ISSUE_CYCLES / 1e9,
                     "unit": "G wave-instructions/s", "frac": None, "traffic": None}

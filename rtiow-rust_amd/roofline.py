@@ -28,6 +28,39 @@ HBM_PEAK_GBS = 8000.0
 XCDS = 8
 
 
+def source_stamp(root):
+    """Identity of the kernel BUILD the counters belong to: the git blob hash (sha1 of "blob <len>\\0" + bytes -- what
+    `git hash-object` prints, computable without a .git directory) of every source the HIP library is compiled from,
+    and one digest over them.  tools/summarize_pmc.py stores it in pmc_summary.json next to the demangled kernel name;
+    bench.py recomputes it from the tree it runs from and refuses to quote counters of another build."""
+    import hashlib
+    csrc = os.path.join(root, "rtiow-rust_amd", "csrc")
+    files = sorted(f for f in os.listdir(csrc) if f.endswith((".h", ".inc", ".hip", ".cpp")) or f == "Makefile")
+    files = [os.path.join("rtiow-rust_amd", "csrc", f) for f in files] + [os.path.join("include", "rtiow_gpu.h")]
+    blobs = {}
+    for rel in files:
+        data = open(os.path.join(root, rel), "rb").read()
+        blobs[rel] = hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+    digest = hashlib.sha1("".join("%s %s\n" % (k, v) for k, v in sorted(blobs.items())).encode()).hexdigest()
+    return {"digest": digest, "blobs": blobs}
+
+
+def profile_staleness(pmc, root, lib_override=None, knobs=None):
+    """None when `pmc` was collected on the build in `root`, else the reason it must not be quoted."""
+    st = pmc.get("build")
+    if not st:
+        return "the profile carries no build stamp (collected before round 3)"
+    if lib_override:
+        return "RTIOW_GPU_LIB points at another build of the library (%s)" % lib_override
+    now = source_stamp(root)
+    if st.get("digest") != now["digest"]:
+        changed = sorted(k for k in set(now["blobs"]) | set(st.get("blobs", {})) if now["blobs"].get(k) != st.get("blobs", {}).get(k))
+        return "kernel sources changed since the counters were collected: " + ", ".join(os.path.basename(c) for c in changed)
+    if knobs:
+        return "schedule options differ from the profiled run: " + ", ".join(knobs)
+    return None
+
+
 def load_pmc(path):
     with open(path) as f:
         return json.load(f)
@@ -41,9 +74,14 @@ def shader_clock_hz(pmc, kernel_s_profiled=None):
     return None
 
 
-def valu_roofline(pmc, kernel_s, samples=None, clock_hz=None, issue_cycles=None):
+def valu_roofline(pmc, kernel_s, samples=None, clock_hz=None, issue_cycles=None, stale=None):
     """pmc: a pmc_summary.json dict; kernel_s: seconds per launch (live HIP events or kernel_stats.csv);
-    samples: samples rendered by the timed launch when it differs from the profiled one (counts scale per sample)."""
+    samples: samples rendered by the timed launch when it differs from the profiled one (counts scale per sample);
+    stale: profile_staleness()'s verdict -- counters of another build give achieved / frac = null and the reason."""
+    if stale:
+        clock = clock_hz or NOMINAL_CLOCK_HZ
+        return {"bound": "valu", "achieved": None, "peak": N_CUS * SIMDS_PER_CU * clock / (issue_cycles or ISSUE_CYCLES) / 1e9,
+                "unit": "G wave-instructions/s", "frac": None, "traffic": None, "stale_profile": stale}
     c = pmc["counters_avg_per_launch"]
     scale = 1.0
     if samples is not None and pmc.get("samples_per_launch"):

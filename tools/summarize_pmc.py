@@ -9,13 +9,18 @@ corrections of MI355X_MICROARCH.md (HBM section): FETCH_SIZE/WRITE_SIZE are in K
 reads by 2x -> doubled.  The shader clock = GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / the duration of the same
 dispatch in the kernel trace of the GRBM pass.
 """
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
 
 
 def main():
     out, workload, kernel, samples = sys.argv[1:5]
     per_counter = collections.defaultdict(lambda: collections.defaultdict(float))
     durations = collections.defaultdict(dict)   # dir -> dispatch id -> seconds
+    names = set()
     for d in sys.argv[5:]:
         for f in glob.glob(d + '/**/*_kernel_trace.csv', recursive=True):
             for r in csv.DictReader(open(f)):
@@ -24,9 +29,16 @@ def main():
         for f in glob.glob(d + '/**/*_counter_collection.csv', recursive=True):
             for r in csv.DictReader(open(f)):
                 if kernel in r['Kernel_Name']:
+                    names.add(r['Kernel_Name'])
                     per_counter[r['Counter_Name']][(d, r['Dispatch_Id'])] += float(r['Counter_Value'])
     summary = {c: sum(v.values()) / len(v) for c, v in per_counter.items()}
     res = {"workload": workload, "kernel": kernel, "samples_per_launch": int(samples), "counters_avg_per_launch": summary}
+    # the BUILD these counters belong to (bench.py / roofline.py refuse to quote them for another one)
+    graft.load_package()
+    from rtiow_rust_amd import roofline as rl
+    res["build"] = rl.source_stamp(ROOT)
+    res["kernel_names"] = sorted(names)
+    res["env_options"] = {k: v for k, v in os.environ.items() if k.startswith("RTG_") or k == "RTIOW_GPU_LIB"}
     if 'FETCH_SIZE' in summary and 'WRITE_SIZE' in summary:
         fetch = summary['FETCH_SIZE'] * 1024 * 2   # KiB -> B, gfx950 x2 correction
         write = summary['WRITE_SIZE'] * 1024
