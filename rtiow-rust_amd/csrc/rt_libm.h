@@ -57,7 +57,7 @@ GL_TAB const uint32_t kGlInvPio4[24] = { 0xa2, 0xa2f9, 0xa2f983, 0xa2f9836e, 0xf
   0x993c4390, 0x3c439041 };
 
 // glibc 2.28+ sysdeps/ieee754/flt-32/e_logf.c (ARM optimized-routines logf): 16-entry table, degree-3 polynomial in double
-GL_FN float rt_logf(float x) {
+__device__ __attribute__((always_inline)) float rt_logf_inline(float x) {
   uint32_t ix = gl_asuint(x);
   if (ix == 0x3f800000u) return 0.f;
   if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
@@ -81,6 +81,8 @@ GL_FN float rt_logf(float x) {
   y = GL_FMA(y, r2, y0 + r);
   return (float)y;
 }
+
+GL_FN float rt_logf(float x) { return rt_logf_inline(x); }
 
 // glibc e_powf.c with y = 5.0f (schlick, material.rs:145): log2 via a 16-entry table + degree-5 polynomial, exp2 via a 32-entry table
 // (a template so that the lean kernel's SCATTER pass can take it inline -- C2 7.97 -> 7.90 ms -- while the full-feature kernels,

@@ -344,10 +344,13 @@ RT_DEV uint4 lds_u4(uint32_t a) {  // 16 bytes at an 8-byte aligned absolute LDS
 
 RT_DEV bool hi_is_root(uint4 hi) { return (hi.w & F_BVH_ROOT) != 0u; }
 
-RT_DEV uint4 fetch_hi_global(const DevScene& sc, uint32_t idx) {  // byte-offset (16 r) skip pointers, global-memory variants
+// Full-feature kernels: a program counter is RSZ x the record index = the record's byte offset in the LDS copy of the program,
+// where (lo, hi) of a record sit side by side (ONE address per fetch: ds_read_b128 v, pc / ds_read_b128 v, pc offset:16).
+constexpr uint32_t RSZ = 32u;
+RT_DEV uint4 fetch_hi_global(const DevScene& sc, uint32_t idx) {  // pc-scaled skip pointers, global-memory variants
   uint4 h = sc.hi[idx];
-  if ((h.w & 0xffu) == OP_BOX) h.z *= 16u;
-  if ((h.w & 0xffu) == OP_MEDIUM) h.x *= 16u;  // end of the boundary's stream
+  if ((h.w & 0xffu) == OP_BOX) h.z *= RSZ;
+  if ((h.w & 0xffu) == OP_MEDIUM) h.x *= RSZ;  // end of the boundary's stream
   return h;
 }
 

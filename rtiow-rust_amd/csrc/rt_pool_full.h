@@ -30,6 +30,9 @@ namespace rtg {
 #define RT_FULL_POOL_SLOTS 224  // 64 in the lanes + rays that wait for company in S, X and N (up to 63 each) + T to refill from;
                                 // book-2: 160 52.6 ms (the lanes starve), 192 45.3, 224 43.9, 256 44.6, 320 45.4
 #endif
+#ifndef RT_FULL_BOX_UNROLL
+#define RT_FULL_BOX_UNROLL 2  // box steps per schedule check (book-2 43.8 -> 43.0 ms)
+#endif
 constexpr uint32_t FPOOL = RT_FULL_POOL_SLOTS;  // paths in flight per wave of the full-feature kernel = capacity of each stack
 enum FullTField : uint32_t {  // T stack: a ray ready to traverse (the *_TRACE rows only exist for the instrumented variant)
   TQ_O = 0, TQ_D = 3, TQ_TIME = 6, TQ_STRENGTH = 7, TQ_BOUNCES = 10, TQ_SAMPLE = 11, TQ_XY = 12, TQ_TRACE = 13, TQ_FIELDS = 16,
@@ -46,7 +49,7 @@ constexpr uint32_t FPOOL_FIELDS = TQ_FIELDS + 2 * SQ_FIELDS + NQ_FIELDS;  // dwo
 inline size_t full_pool_lds_bytes(uint32_t window, uint32_t /*waves*/) { return (size_t)window * 32; }
 
 // draw `idx` (0-based) of the stream (seed, pixel, sample, event): word idx%4 of Philox block idx/4
-__device__ __attribute__((noinline)) float event_draw_f32(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t event, uint32_t idx) {
+__device__ __attribute__((always_inline)) float event_draw_f32_inline(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t event, uint32_t idx) {
   SampleRng r;
   r.init(seed, pixel, sample);
   r.set_event(event);
@@ -57,6 +60,9 @@ __device__ __attribute__((noinline)) float event_draw_f32(uint64_t seed, uint32_
   return (float)(u >> 8) * (1.0f / 16777216.0f);
 }
 
+__device__ __attribute__((noinline)) float event_draw_f32(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t event, uint32_t idx) {
+  return event_draw_f32_inline(seed, pixel, sample, event, idx);
+}
 // PROG: 0 = program fetched from global memory (L1/L2), 1 = whole program staged in LDS, 2 = an LDS
 // window over the first `window` records (depth-first order, so it holds whole leading subtrees) and global memory for the
 // rest (book-2's 4 213 records = 134.8 KB fit whole).
@@ -73,8 +79,8 @@ RT_DEV QueueRsrc make_queue_rsrc(uint32_t* wave_base) {
   return __builtin_amdgcn_make_buffer_rsrc(wave_base, 0, FPOOL * FPOOL_FIELDS * 4u, 0x00020000);
 }
 #define RT_IN_LDS(pc_) (PROG == 1 || (PROG == 2 && (pc_) < win_bytes))
-#define RT_FETCH_LO(pc_) (RT_IN_LDS(pc_) ? *reinterpret_cast<const uint4*>(s_bytes + (pc_)) : sc.lo[(pc_) >> 4])
-#define RT_FETCH_HI(pc_) (RT_IN_LDS(pc_) ? *reinterpret_cast<const uint4*>(s_bytes + win_bytes + (pc_)) : fetch_hi_global(sc, (pc_) >> 4))
+#define RT_FETCH_LO(pc_) (RT_IN_LDS(pc_) ? *reinterpret_cast<const uint4*>(s_bytes + (pc_)) : sc.lo[(pc_) >> 5])
+#define RT_FETCH_HI(pc_) (RT_IN_LDS(pc_) ? *reinterpret_cast<const uint4*>(s_bytes + (pc_) + 16u) : fetch_hi_global(sc, (pc_) >> 5))
 // Stack records are addressed through ONE buffer resource per wave (`qr`: base = the wave's stack space, in SGPRs) with the
 // position as the only VGPR of an access and the row as a constant offset -- no 64-bit address arithmetic, no address registers.
 #define Q_ROW(base_, f_) (((base_) + (f_)) * FPOOL * 4u)  /* byte offset of a row */
@@ -141,14 +147,14 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   constexpr uint32_t OP_SLOW_LAST = GENB ? (uint32_t)OP_BEND : (uint32_t)OP_PRISM;  // records a slow pass executes
   constexpr uint32_t STACK_LEVELS = GENB ? 2 * MAX_XFORM_DEPTH : MAX_XFORM_DEPTH;   // a boundary stream nests below the medium's own wrappers
   constexpr bool USE_LDS = PROG != 0;
-  const uint32_t win_bytes = 16u * window;
+  const uint32_t win_bytes = RSZ * window;
   if (USE_LDS) {
     for (uint32_t i = threadIdx.x; i < window; i += blockDim.x) {
       uint4 h = sc.hi[i];
-      if ((h.w & 0xffu) == OP_BOX) h.z *= 16u;
-      if ((h.w & 0xffu) == OP_MEDIUM) h.x *= 16u;
-      s_mem[i] = sc.lo[i];
-      s_mem[window + i] = h;
+      if ((h.w & 0xffu) == OP_BOX) h.z *= RSZ;
+      if ((h.w & 0xffu) == OP_MEDIUM) h.x *= RSZ;
+      s_mem[2u * i] = sc.lo[i];
+      s_mem[2u * i + 1u] = h;
     }
   }
   const char* s_bytes = reinterpret_cast<const char*>(s_mem);
@@ -167,6 +173,8 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   uint32_t w_next = 0, w_end = 0, w_chunk = 0, w_delta = 0;
   bool w_lpt_ready = false;
   bool exhausted = false;
+  const unsigned long long t_start = RT_TICK();
+  unsigned long long t_exhausted = 0;
 
   // ---- per-lane traversal state ---------------------------------------------------------------
   bool have_ray = false;
@@ -386,6 +394,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
             base = __builtin_amdgcn_readfirstlane(base);
             if (base >= total_work) {
               exhausted = true;
+              if (COUNT) t_exhausted = RT_TICK();
             } else {
               w_chunk = lpt_reservation(cm, base, lane, w_delta, w_lpt_ready);
               w_next = base;
@@ -512,6 +521,10 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
       atomicAdd(&counters[6], t_fin), atomicAdd(&counters[5], n_serv);
       atomicAdd(&counters[16], t_shade), atomicAdd(&counters[17], t_serv - t_shade), atomicAdd(&counters[18], t_box),
           atomicAdd(&counters[19], t_slow);
+      // wave timeline (rt_pool.h)
+      const unsigned long long dur = RT_TICK() - t_start, exh = t_exhausted - t_start;
+      atomicMax(&counters[24], dur), atomicAdd(&counters[25], dur), atomicAdd(&counters[26], 1ull);
+      atomicMax(&counters[27], (1ull << 62) - exh), atomicAdd(&counters[28], exh), atomicMax(&counters[29], exh);
     }
   }
 }

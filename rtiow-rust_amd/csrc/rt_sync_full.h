@@ -20,20 +20,20 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   constexpr uint32_t OP_SLOW_LAST = GENB ? (uint32_t)OP_BEND : (uint32_t)OP_PRISM;
   constexpr uint32_t STACK_LEVELS = GENB ? 2 * MAX_XFORM_DEPTH : MAX_XFORM_DEPTH;
   constexpr bool USE_LDS = PROG != 0;
-  const uint32_t win_bytes = 16u * window;
+  const uint32_t win_bytes = RSZ * window;
   if (USE_LDS) {
     for (uint32_t i = threadIdx.x; i < window; i += blockDim.x) {
       uint4 h = sc.hi[i];
-      if ((h.w & 0xffu) == OP_BOX) h.z *= 16u;
-      if ((h.w & 0xffu) == OP_MEDIUM) h.x *= 16u;
-      s_mem[i] = sc.lo[i];
-      s_mem[window + i] = h;
+      if ((h.w & 0xffu) == OP_BOX) h.z *= RSZ;
+      if ((h.w & 0xffu) == OP_MEDIUM) h.x *= RSZ;
+      s_mem[2u * i] = sc.lo[i];
+      s_mem[2u * i + 1u] = h;
     }
   }
   const char* s_bytes = reinterpret_cast<const char*>(s_mem);
 #define RT_IN_LDS(pc_) (PROG == 1 || (PROG == 2 && (pc_) < win_bytes))
-#define RT_FETCH_LO(pc_) (RT_IN_LDS(pc_) ? *reinterpret_cast<const uint4*>(s_bytes + (pc_)) : sc.lo[(pc_) >> 4])
-#define RT_FETCH_HI(pc_) (RT_IN_LDS(pc_) ? *reinterpret_cast<const uint4*>(s_bytes + win_bytes + (pc_)) : fetch_hi_global(sc, (pc_) >> 4))
+#define RT_FETCH_LO(pc_) (RT_IN_LDS(pc_) ? *reinterpret_cast<const uint4*>(s_bytes + (pc_)) : sc.lo[(pc_) >> 5])
+#define RT_FETCH_HI(pc_) (RT_IN_LDS(pc_) ? *reinterpret_cast<const uint4*>(s_bytes + (pc_) + 16u) : fetch_hi_global(sc, (pc_) >> 5))
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, n_waves = blockDim.x >> 6;
   const size_t gwave = (size_t)blockIdx.x * n_waves + wave;
   float* stack = g_stack + gwave * (STACK_LEVELS * 6 * 64);  // [level][component][lane]
