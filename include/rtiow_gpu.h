@@ -32,7 +32,7 @@ extern "C" {
 #define RTG_ERR_EMPTY_BVH (-2)   /* bvh.rs:60 panic "Can't create a BVH from zero objects."          */
 #define RTG_ERR_NAN (-3)         /* bvh.rs:45,56 partial_cmp().unwrap() panic on NaN extents          */
 #define RTG_ERR_RANGE (-4)       /* camera.rs:55 gen_range(lo,hi) asserts lo < hi                     */
-#define RTG_ERR_UNSUPPORTED (-5) /* object graph shape the flattened GPU program cannot express       */
+#define RTG_ERR_UNSUPPORTED (-5) /* nesting beyond the general walk's stacks (32 wrappers, 3 media levels) */
 #define RTG_ERR_DEVICE (-6)      /* HIP runtime error / no GPU                                         */
 
 typedef uint32_t rtg_id;

@@ -41,6 +41,10 @@ enum Op : uint32_t {
   OP_BEND = 8,    // hi = (-, -, medium_pc, op): end of the record stream of a MEDIUM whose boundary is an object graph
                   //      (F_GENERAL_BOUNDARY).  The main walk never reaches it (MEDIUM.end_pc points behind it); a walk that
                   //      runs the boundary's stream as a range query (rt_pool_full.h GENB) finishes the query here.
+  // Only in programs with FEAT_DEEP (graph shapes the scheduled kernels do not walk; the general walk of rt_trace.h does):
+  OP_SAVE = 9,    // in front of the stream of an `And` that sits below a Bvh and holds a ConstantMedium: remember the hit so far
+  OP_MERGE = 10,  // behind it: bvh.rs:104-112 for that leaf -- the earlier hit `hl` wins when hl.t < hr.t (only a medium can
+                  // return t >= t_range.end; inside the And itself the later hit replaces, object.rs:403-409)
 };
 
 // flag bits in hi.w above the 8-bit opcode
@@ -66,7 +70,10 @@ enum XformKind : uint32_t {
   XF_FLIP = 4,       //                                  object.rs:241-253
 };
 
-constexpr int MAX_XFORM_DEPTH = 4;  // PUSH nesting the kernel's ray stack holds (a medium's boundary stream starts a fresh count)
+constexpr int MAX_XFORM_DEPTH = 4;  // PUSH nesting the scheduled kernels' ray stack holds (a medium's boundary stream starts a fresh count)
+constexpr int MAX_DEEP_XFORM_DEPTH = 32;  // ... and the general walk's (FEAT_DEEP)
+constexpr int MAX_MEDIUM_NESTING = 3;     // media inside the boundary of a medium inside ...: levels the general walk follows
+constexpr int MAX_SAVE_NESTING = 4;       // OP_SAVE .. OP_MERGE pairs inside one another
 
 // Material record, 32 bytes (two uint4): lo = (c.r, c.g, c.b, param) hi = (texture, -, -, kind|texkind<<8)
 //   Lambertian / Isotropic: c = albedo when the texture is constant, else `texture` indexes tex[]
@@ -82,6 +89,8 @@ constexpr uint32_t FEAT_MEDIUM = 2u;   // MEDIUM present
 constexpr uint32_t FEAT_RECT = 4u;     // RECT present
 constexpr uint32_t FEAT_TEXTURE = 8u;  // a non-constant texture is referenced
 constexpr uint32_t FEAT_BOUNDARY = 16u; // a ConstantMedium whose boundary is an object graph (nested boundary walk)
+constexpr uint32_t FEAT_DEEP = 128u;   // a graph shape only the general walk handles (rt_trace.h walk_deep, baseline kernel): more than MAX_XFORM_DEPTH
+                                       // nested wrappers, a medium inside a medium's boundary, a medium below an And below a Bvh
 constexpr uint32_t FEAT_BRIGHT_ALBEDO = 64u; // an albedo component may exceed 1 (a constant in (1, 4], or Perlin turbulence, <= 3.47): the pool
                                             // kernels then need max_bounces <= 63 for the strength to stay finite
 constexpr uint32_t FEAT_WIDE_ALBEDO = 32u;  // an albedo component outside [0, 4]: path strength may overflow or change sign, so the pool

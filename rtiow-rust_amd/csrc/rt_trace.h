@@ -233,12 +233,193 @@ __device__ __attribute__((noinline)) BoundaryHit boundary_hit_t(const uint4* __r
   return BoundaryHit{best, any ? 1u : 0u, n_aabb, n_prim};
 }
 
+// The GENERAL walk (programs with FEAT_DEEP: more than MAX_XFORM_DEPTH nested wrappers, a ConstantMedium inside another
+// medium's boundary, a medium below an `And` below a Bvh).  One function serves the main walk (LEVEL 0, `rec` != null: keeps the
+// hit record, lib.rs:33-55) and the boundary queries of ConstantMedium::hit (object.rs:551-552; LEVEL >= 1, `rec` == null: only
+// the closest t matters) -- a medium met at LEVEL n runs its two queries at LEVEL n + 1 over its boundary's record stream, with
+// the event's RNG stream handed down so that the draws happen in the reference's order (object.rs:562).  Same predicates,
+// same visiting order, same counters as hit_top / boundary_hit_t; one lane per ray, private stacks: the slow, general path.
+template <int LEVEL, bool COUNT>
+__device__ __attribute__((noinline)) bool walk_deep(const DevScene& sc, uint32_t first, uint32_t end_pc, V3 o, V3 d, const float time,
+                                                    const float t_lo, const float t_hi, SampleRng& rng, HitRec* rec, float& t_out,
+                                                    Counts& cnt) {
+  V3 inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+  float best = t_hi;
+  bool any = false;
+  int depth = 0, tag = 0, sp = 0;
+  uint32_t nhits = 0, root_hits = 0;
+  V3 so[MAX_DEEP_XFORM_DEPTH], sd[MAX_DEEP_XFORM_DEPTH];
+  // OP_SAVE .. OP_MERGE: the hit in front of an And-with-medium leaf of a Bvh
+  float sv_best[MAX_SAVE_NESTING];
+  HitRec sv_rec[MAX_SAVE_NESTING];
+  int sv_tag[MAX_SAVE_NESTING];
+  uint32_t sv_nhits[MAX_SAVE_NESTING], sv_root[MAX_SAVE_NESTING];
+  bool sv_any[MAX_SAVE_NESTING];
+  uint32_t pc = first;
+  while (pc < end_pc) {
+    const uint4 hi = sc.hi[pc];
+    const uint32_t op = hi.w & 0xffu;
+    if (op == OP_END) break;
+    const uint4 lo = sc.lo[pc];
+    if (op == OP_BOX) {  // Aabb::hit, aabb.rs:16-27
+      if (COUNT) cnt.aabb++;
+      if (hi.w & F_BVH_ROOT) root_hits = nhits;
+      float t0x = (u2f(lo.x) - o.x) * inv.x, t1x = (u2f(lo.y) - o.x) * inv.x;
+      float t0y = (u2f(lo.z) - o.y) * inv.y, t1y = (u2f(lo.w) - o.y) * inv.y;
+      float t0z = (u2f(hi.x) - o.z) * inv.z, t1z = (u2f(hi.y) - o.z) * inv.z;
+      float ax = inv.x < 0.f ? t1x : t0x, bx = inv.x < 0.f ? t0x : t1x;
+      float ay = inv.y < 0.f ? t1y : t0y, by = inv.y < 0.f ? t0y : t1y;
+      float az = inv.z < 0.f ? t1z : t0z, bz = inv.z < 0.f ? t0z : t1z;
+      float start = rs_max(t_lo, rs_max(rs_max(ax, ay), az));
+      float end = rs_min(best, rs_min(rs_min(bx, by), bz));
+      pc = (end > start) ? pc + 1 : hi.z;
+    } else if (op == OP_SPHERE) {
+      if (COUNT) cnt.prim++;
+      V3 off = mk(u2f(lo.x), u2f(lo.y), u2f(lo.z));
+      V3 lo_o = o;
+      if (hi.w & F_TRANSLATE) lo_o = vsub(o, off);
+      float t;
+      if (sphere_hit_t(lo_o, d, u2f(lo.w), t_lo, best, t)) {
+        if (rec) {
+          V3 p = vadd(lo_o, smul(t, d));
+          V3 n = sdiv(p, u2f(lo.w));
+          if (hi.w & F_TRANSLATE) p = vadd(p, off);
+          if (hi.w & F_FLIP) n = vneg(n);
+          rec->t = t, rec->p = p, rec->n = n, rec->mat = hi.z;
+        }
+        best = t, any = true, tag = depth, nhits++;
+      }
+      pc++;
+    } else if (op == OP_RECT) {
+      if (COUNT) cnt.prim++;
+      uint32_t axis = (hi.w >> F_AXIS_SHIFT) & 3u;
+      float t;
+      if (rect_hit_t(o, d, axis, u2f(lo.x), u2f(lo.y), u2f(lo.z), u2f(lo.w), u2f(hi.x), t_lo, best, t)) {
+        if (rec) {
+          V3 n = mk(axis == 0 ? 1.f : 0.f, axis == 1 ? 1.f : 0.f, axis == 2 ? 1.f : 0.f);
+          if (hi.w & F_FLIP) n = vneg(n);
+          rec->t = t, rec->p = vadd(o, smul(t, d)), rec->n = n, rec->mat = hi.z;
+        }
+        best = t, any = true, tag = depth, nhits++;
+      }
+      pc++;
+    } else if (op == OP_PRISM) {
+      if (COUNT) cnt.prim += 6;
+      float t;
+      uint32_t face = 0;
+      const uint32_t nh = prism_hit_t(lo, hi, o, d, t_lo, best, t, face);
+      if (nh) {
+        if (rec) rec->t = t, rec->p = vadd(o, smul(t, d)), rec->n = prism_normal(face), rec->mat = hi.z;
+        best = t, any = true, tag = depth, nhits += nh;
+      }
+      pc++;
+    } else if (op == OP_PUSH) {
+      uint32_t kind = (hi.w >> F_KIND_SHIFT) & 7u;
+      so[depth] = o, sd[depth] = d;
+      depth++;
+      V3 a = mk(u2f(lo.x), u2f(lo.y), u2f(lo.z));
+      if (hi.w & F_PRE_TRANSLATE) o = vsub(o, mk(u2f(lo.w), u2f(hi.x), u2f(hi.y)));
+      if (kind == XF_TRANSLATE) {
+        o = vsub(o, a);
+      } else if (kind == XF_ROTATE_Y) {
+        o = rot_y(o, -a.x, a.y), d = rot_y(d, -a.x, a.y);
+        inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+      } else if (kind == XF_SCALE) {
+        o = vdiv(o, a), d = vdiv(d, a);
+        inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+      } else if (kind == XF_MOVE) {
+        o = vsub(o, smul(time, a));
+      }
+      pc++;
+    } else if (op == OP_POP) {
+      uint32_t kind = (hi.w >> F_KIND_SHIFT) & 7u;
+      depth--;
+      if (rec && any && tag == depth + 1) {  // the current best hit was found inside this wrapper
+        V3 a = mk(u2f(lo.x), u2f(lo.y), u2f(lo.z));
+        if (kind == XF_TRANSLATE) {
+          rec->p = vadd(rec->p, a);
+        } else if (kind == XF_ROTATE_Y) {
+          rec->p = rot_y(rec->p, a.x, a.y), rec->n = rot_y(rec->n, a.x, a.y);
+        } else if (kind == XF_SCALE) {
+          rec->p = vmul(rec->p, a), rec->n = vdiv(rec->n, a);
+        } else if (kind == XF_FLIP) {
+          rec->n = vneg(rec->n);
+        }
+        if (hi.w & F_PRE_TRANSLATE) rec->p = vadd(rec->p, mk(u2f(lo.w), u2f(hi.x), u2f(hi.y)));
+      }
+      if (any && tag == depth + 1) tag = depth;
+      o = so[depth], d = sd[depth];
+      if (kind == XF_ROTATE_Y || kind == XF_SCALE) inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+      pc++;
+    } else if (op == OP_MEDIUM) {  // ConstantMedium::hit, object.rs:545-575
+      const bool general = (hi.w & F_GENERAL_BOUNDARY) != 0u;
+      const uint4 blo = sc.lo[pc + 1], bhi = sc.hi[pc + 1];
+      float t1 = 0.f, t2 = 0.f;
+      bool h1 = false, h2 = false;
+      if (general) {
+        if constexpr (LEVEL < MAX_MEDIUM_NESTING) h1 = walk_deep<LEVEL + 1, COUNT>(sc, pc + 1, hi.x, o, d, time, -F32_MAX, F32_MAX, rng, nullptr, t1, cnt);
+      } else {
+        if (COUNT) cnt.prim++;
+        h1 = prim_hit_t(blo, bhi, o, d, -F32_MAX, F32_MAX, t1);
+      }
+      if (h1) {
+        if (general) {
+          if constexpr (LEVEL < MAX_MEDIUM_NESTING) h2 = walk_deep<LEVEL + 1, COUNT>(sc, pc + 1, hi.x, o, d, time, t1 + 0.0001f, F32_MAX, rng, nullptr, t2, cnt);
+        } else {
+          if (COUNT) cnt.prim++;
+          h2 = prim_hit_t(blo, bhi, o, d, t1 + 0.0001f, F32_MAX, t2);
+        }
+        if (h2) {
+          t1 = rs_max(t1, t_lo);
+          t2 = rs_min(t2, best);
+          if (!(t1 >= t2)) {
+            float distance_inside = (t2 - t1) * vlen(d);
+            float hit_distance = -(1.f / u2f(lo.x)) * rt_logf(rng.gen_f32());
+            if (hit_distance < distance_inside) {
+              float t = t1 + hit_distance / vlen(d);
+              bool accept = !(hi.w & F_UNDER_BVH) || nhits == root_hits || !(best < t);  // merge rule: see hit_top
+              if (accept) {
+                if (rec) rec->t = t, rec->p = vadd(o, smul(t, d)), rec->n = mk(1.f, 0.f, 0.f), rec->mat = hi.z;
+                best = t, any = true, tag = depth, nhits++;
+              }
+            }
+          }
+        }
+      }
+      pc = hi.x;  // first record after the boundary's stream
+    } else if (op == OP_SAVE) {
+      sv_best[sp] = best, sv_any[sp] = any, sv_tag[sp] = tag, sv_nhits[sp] = nhits, sv_root[sp] = root_hits;
+      if (rec) sv_rec[sp] = *rec;
+      sp++;
+      pc++;
+    } else if (op == OP_MERGE) {  // bvh.rs:104-112 for the leaf that ends here: (Some(hl), Some(hr)) => if hl.t < hr.t { hl } else { hr }
+      sp--;
+      const bool leaf_hit = nhits != sv_nhits[sp];            // hr
+      const bool earlier = sv_nhits[sp] != sv_root[sp];       // hl: a hit inside the same outermost Bvh, in front of this leaf
+      if (leaf_hit && earlier && sv_best[sp] < best) {
+        best = sv_best[sp], tag = sv_tag[sp];
+        if (rec) *rec = sv_rec[sp];
+      }
+      root_hits = sv_root[sp];
+      pc++;
+    } else {
+      pc++;  // OP_BEND (end of a boundary stream)
+    }
+  }
+  t_out = best;
+  return any;
+}
+
 // World::hit_top (lib.rs:33-55) over the flat program.  `best` plays `nearest` / the shrinking
 // t_range.end; t_range.start is always t_near.  Returns Some/None, fills `rec` (world space).
 template <uint32_t FEAT, bool COUNT>
 RT_DEV bool hit_top(const DevScene& sc, V3 o, V3 d, float time, float t_near, SampleRng& rng,
                     HitRec& rec, Counts& cnt) {
   if (COUNT) cnt.rays++;
+  if (FEAT & FEAT_DEEP) {  // graph shapes only the general walk handles
+    float t;
+    return walk_deep<0, COUNT>(sc, 0u, sc.n_prog, o, d, time, t_near, F32_MAX, rng, &rec, t, cnt);
+  }
   V3 inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);  // aabb.rs:17, hoisted: depends on the ray only
   float best = F32_MAX;
   bool any = false;

@@ -533,7 +533,8 @@ static hipError_t launch_render(rtg_scene* s, const DevCamera& cam, const DevPar
   // is +0" argument holds (rt_pool.h PoolField)
   const uint32_t geom = s->features & (FEAT_ALL | FEAT_BOUNDARY);
   const bool accum_zero = !(s->features & FEAT_WIDE_ALBEDO) && (!(s->features & FEAT_BRIGHT_ALBEDO) || d.max_bounces <= 63u);
-  const bool pool_ok = accum_zero && s->kernel_version >= 3 && d.nx <= 0xffffu && d.ny <= 0xffffu;
+  // FEAT_DEEP: graph shapes only the general walk of the baseline kernel handles (flat_scene.h)
+  const bool pool_ok = accum_zero && s->kernel_version >= 3 && d.nx <= 0xffffu && d.ny <= 0xffffu && !(s->features & FEAT_DEEP);
   s->last_kernel = 1;
   if (geom != 0 && pool_ok) {
     s->last_kernel = 4;
@@ -545,7 +546,9 @@ static hipError_t launch_render(rtg_scene* s, const DevCamera& cam, const DevPar
   }
   uint32_t nbx = (d.nx + 15) / 16, nby = (d.ny + 15) / 16;
   dim3 grid(nbx * nby), block(256);
-  if (geom == 0)
+  if (s->features & FEAT_DEEP)
+    hipLaunchKernelGGL((render_kernel<FEAT_ALL | FEAT_DEEP, COUNT>), grid, block, 0, stream, s->dev, cam, d, d_out, s->d_counters);
+  else if (geom == 0)
     hipLaunchKernelGGL((render_kernel<0u, COUNT>), grid, block, 0, stream, s->dev, cam, d, d_out, s->d_counters);
   else
     hipLaunchKernelGGL((render_kernel<FEAT_ALL, COUNT>), grid, block, 0, stream, s->dev, cam, d, d_out, s->d_counters);
@@ -1331,7 +1334,10 @@ int rtg_debug_hit_top(rtg_scene* s, size_t n, const float* rays, uint64_t seed, 
   HIP_TRY(hipMemcpy(d_rays.p, rays, 7 * n * sizeof(float), hipMemcpyHostToDevice));
   dim3 grid((uint32_t)((n + 63) / 64)), block(64);
   if (n) {
-    if (s->features == 0)
+    if (s->features & FEAT_DEEP)
+      hipLaunchKernelGGL((debug_hit_top_kernel<FEAT_ALL | FEAT_DEEP>), grid, block, 0, 0, s->dev, (uint32_t)n, d_rays.p, (uint32_t)seed,
+                         (uint32_t)(seed >> 32), t_near, d_out.p, d_mat.p);
+    else if (s->features == 0)
       hipLaunchKernelGGL((debug_hit_top_kernel<0u>), grid, block, 0, 0, s->dev, (uint32_t)n, d_rays.p, (uint32_t)seed,
                          (uint32_t)(seed >> 32), t_near, d_out.p, d_mat.p);
     else
@@ -1410,7 +1416,10 @@ int rtg_debug_samples(rtg_scene* s, const rtg_camera* camera, const rtg_params* 
   DevCamera cam = to_dev(camera);
   dim3 grid((uint32_t)((n + 63) / 64)), block(64);
   if (n) {
-    if (s->features == 0)
+    if (s->features & FEAT_DEEP)
+      hipLaunchKernelGGL((debug_samples_kernel<FEAT_ALL | FEAT_DEEP>), grid, block, 0, 0, s->dev, cam, d, (uint32_t)n, dx.p, dy.p, ds.p,
+                         drgb.p, dinfo.p);
+    else if (s->features == 0)
       hipLaunchKernelGGL((debug_samples_kernel<0u>), grid, block, 0, 0, s->dev, cam, d, (uint32_t)n, dx.p, dy.p, ds.p,
                          drgb.p, dinfo.p);
     else

@@ -310,20 +310,44 @@ static bool match_prism(const SceneBuilder& b, uint32_t id, float p0[3], float p
   return true;
 }
 
-void SceneBuilder::emit_bvh(int32_t node_id, int depth, FlatScene* out, bool in_boundary) const {
+bool SceneBuilder::holds_medium(uint32_t id) const {
+  const HostObject& o = objects[id];
+  switch (o.kind) {
+    case HostObject::MEDIUM: return true;
+    case HostObject::SPHERE:
+    case HostObject::RECT: return false;
+    case HostObject::AND: return holds_medium(o.a) || holds_medium(o.b);
+    case HostObject::BVH: {
+      std::vector<int32_t> todo(1, (int32_t)o.a);
+      while (!todo.empty()) {
+        const HostBvhNode& n = bvh_nodes[todo.back()];
+        todo.pop_back();
+        if (n.leaf != kNone) {
+          if (holds_medium(n.leaf)) return true;
+        } else {
+          todo.push_back(n.left), todo.push_back(n.right);
+        }
+      }
+      return false;
+    }
+    default: return holds_medium(o.a);  // wrappers
+  }
+}
+
+void SceneBuilder::emit_bvh(int32_t node_id, int depth, FlatScene* out, int boundary, bool mark_roots, int saves) const {
   const HostBvhNode& n = bvh_nodes[node_id];
   size_t at = out->lo.size();
   push(out, n.box.mn[0], n.box.mx[0], n.box.mn[1], n.box.mx[1], fbits(n.box.mn[2]), fbits(n.box.mx[2]), 0, OP_BOX);
   if (n.leaf != kNone) {
-    emit(n.leaf, true, false, depth, out, in_boundary);
+    emit(n.leaf, true, depth, out, boundary, mark_roots, saves);
   } else {
-    emit_bvh(n.left, depth, out, in_boundary);
-    emit_bvh(n.right, depth, out, in_boundary);
+    emit_bvh(n.left, depth, out, boundary, mark_roots, saves);
+    emit_bvh(n.right, depth, out, boundary, mark_roots, saves);
   }
   out->hi[at].w[2] = (uint32_t)out->lo.size();  // skip pointer: first instruction after the subtree
 }
 
-void SceneBuilder::emit(uint32_t id, bool under_bvh, bool and_in_bvh, int depth, FlatScene* out, bool in_boundary) const {
+void SceneBuilder::emit(uint32_t id, bool under_bvh, int depth, FlatScene* out, int boundary, bool mark_roots, int saves) const {
   const HostObject& o = objects[id];
   if (fuse_primitive(*this, id, out, true)) return;
   switch (o.kind) {
@@ -335,21 +359,39 @@ void SceneBuilder::emit(uint32_t id, bool under_bvh, bool and_in_bvh, int depth,
         out->features |= FEAT_RECT;
         return;
       }
+      if (under_bvh && holds_medium(id)) {
+        // `And` below a Bvh with a ConstantMedium inside.  Inside the And the later hit replaces the earlier one whatever
+        // its t (object.rs:403-409); the Bvh node above compares (bvh.rs:104-112), and a medium may return t >= t_range.end.
+        // The flat stream says so with a SAVE / MERGE pair around the And's stream, whose own objects are emitted as a
+        // list's (media replace; Bvhs inside are outermost ones again).  Only the general walk executes these two records.
+        if (saves >= MAX_SAVE_NESTING)
+          throw BuildError{-5, "And-with-medium leaves of Bvhs nested deeper than the general walk's save stack (4)"};
+        out->features |= FEAT_DEEP;
+        push(out, 0, 0, 0, 0, 0, 0, 0, OP_SAVE);
+        emit(o.a, false, depth, out, boundary, true, saves + 1);
+        emit(o.b, false, depth, out, boundary, true, saves + 1);
+        push(out, 0, 0, 0, 0, 0, 0, 0, OP_MERGE);
+        return;
+      }
     }
-      emit(o.a, under_bvh, under_bvh, depth, out, in_boundary);
-      emit(o.b, under_bvh, under_bvh, depth, out, in_boundary);
+      emit(o.a, under_bvh, depth, out, boundary, mark_roots, saves);
+      emit(o.b, under_bvh, depth, out, boundary, mark_roots, saves);
       return;
     case HostObject::BVH: {
       size_t root = out->lo.size();
-      emit_bvh((int32_t)o.a, depth, out, in_boundary);
-      if (!under_bvh && !in_boundary) out->hi[root].w[3] |= F_BVH_ROOT;  // (a boundary query keeps no hit record: no merge rule)
+      emit_bvh((int32_t)o.a, depth, out, boundary, mark_roots, saves);
+      // (a boundary query of the scheduled kernels keeps no hit count: no merge rule there, roots stay unmarked)
+      if (!under_bvh && mark_roots) out->hi[root].w[3] |= F_BVH_ROOT;
       return;
     }
     case HostObject::MEDIUM: {
-      if (and_in_bvh)
-        throw BuildError{-5, "ConstantMedium below an And below a Bvh is not expressible in the flat program"};
-      if (in_boundary)
-        throw BuildError{-5, "a ConstantMedium inside another medium's boundary is not expressible in the flat program"};
+      if (boundary > 0) {
+        // a ConstantMedium inside another medium's boundary (`ConstantMedium<O: Object>`, object.rs:533-575, with O holding a
+        // medium): the general walk follows MAX_MEDIUM_NESTING levels of boundary queries
+        if (boundary >= MAX_MEDIUM_NESTING)
+          throw BuildError{-5, "media nested in media boundaries deeper than the general walk follows (3)"};
+        out->features |= FEAT_DEEP;
+      }
       {
         const size_t at = out->lo.size();
         const bool single = fuse_primitive(*this, o.a, out, false);
@@ -360,7 +402,7 @@ void SceneBuilder::emit(uint32_t id, bool under_bvh, bool and_in_bvh, int depth,
         if (single) {
           fuse_primitive(*this, o.a, out, true);
         } else {
-          emit(o.a, false, false, 0, out, true), out->features |= FEAT_BOUNDARY;
+          emit(o.a, false, 0, out, boundary + 1, holds_medium(o.a), 0), out->features |= FEAT_BOUNDARY;
           push(out, 0, 0, 0, 0, 0, 0, (uint32_t)at, OP_BEND);  // where a range-query walk of the stream finishes
         }
         out->hi[at].w[0] = (uint32_t)out->lo.size();  // end_pc
@@ -380,8 +422,9 @@ void SceneBuilder::emit(uint32_t id, bool under_bvh, bool and_in_bvh, int depth,
     case HostObject::FLIP: kind = XF_FLIP; break;
     default: throw BuildError{-1, "flatten: unknown object kind"};
   }
-  if (depth >= MAX_XFORM_DEPTH)
-    throw BuildError{-5, "transform wrappers nested deeper than the kernel's ray stack (4)"};
+  if (depth >= MAX_DEEP_XFORM_DEPTH)
+    throw BuildError{-5, "transform wrappers nested deeper than the general walk's ray stack (32)"};
+  if (depth >= MAX_XFORM_DEPTH) out->features |= FEAT_DEEP;  // deeper than the scheduled kernels' ray stack: the general walk
   out->features |= FEAT_XFORM;
   // Translate{RotateY{x}} / Translate{LinearMove{x}} (every transformed object of main.rs): one wrapper level
   const HostObject* w = &o;
@@ -395,7 +438,7 @@ void SceneBuilder::emit(uint32_t id, bool under_bvh, bool and_in_bvh, int depth,
   }
   size_t at = out->lo.size();
   push(out, w->f[0], w->f[1], w->f[2], pre[0], fbits(pre[1]), fbits(pre[2]), 0, OP_PUSH | (kind << F_KIND_SHIFT) | pre_flag);
-  emit(w->a, under_bvh, and_in_bvh, depth + 1, out, in_boundary);
+  emit(w->a, under_bvh, depth + 1, out, boundary, mark_roots, saves);
   out->hi[at].w[2] = (uint32_t)out->lo.size();
   push(out, w->f[0], w->f[1], w->f[2], pre[0], fbits(pre[1]), fbits(pre[2]), (uint32_t)at, OP_POP | (kind << F_KIND_SHIFT) | pre_flag);
 }
@@ -414,7 +457,7 @@ void SceneBuilder::flatten(const uint32_t* world, size_t n, FlatScene* out) cons
   for (size_t i = 0; i < n; i++) {
     if (world[i] >= objects.size()) throw BuildError{-1, "scene: bad world object handle"};
     const size_t at = out->lo.size();
-    emit(world[i], false, false, 0, out);
+    emit(world[i], false, 0, out);
     bool has_box = false;
     for (size_t r = at; r < out->lo.size(); r++) has_box |= (out->hi[r].w[3] & 0xffu) == OP_BOX;
     if (has_box) {

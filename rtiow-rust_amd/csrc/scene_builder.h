@@ -75,8 +75,11 @@ class SceneBuilder {
  private:
   int32_t build_bvh(std::vector<uint32_t> objs, float e0, float e1);
   int32_t build_bvh_sah(std::vector<uint32_t> objs, float e0, float e1);
-  void emit(uint32_t obj, bool under_bvh, bool under_and_in_bvh, int depth, FlatScene* out, bool in_boundary = false) const;
-  void emit_bvh(int32_t node, int depth, FlatScene* out, bool in_boundary) const;
+  // `boundary` = nesting level of medium boundaries the stream belongs to (0 = the main walk); `mark_roots`: outermost Bvhs of
+  // this stream get F_BVH_ROOT (always in the main walk; in a boundary stream only when it holds a medium itself)
+  void emit(uint32_t obj, bool under_bvh, int depth, FlatScene* out, int boundary = 0, bool mark_roots = true, int saves = 0) const;
+  void emit_bvh(int32_t node, int depth, FlatScene* out, int boundary, bool mark_roots, int saves) const;
+  bool holds_medium(uint32_t obj) const;
 };
 
 struct BuildError {

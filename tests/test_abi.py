@@ -193,18 +193,41 @@ def test_reference_error_behaviour(pkg):
         b.perlin(4.0)                                    # tables not supplied
     with pytest.raises(pkg.RtError):
         b.rect(5, (0, 1), (0, 1), 0.0, m)
-    # shapes the flat program cannot express are refused, never silently approximated
+    # Every graph the reference's types allow flattens.  Shapes the scheduled kernels do not walk (a medium inside a medium's
+    # boundary, a medium below an And below a Bvh, more than 4 nested wrappers) set FEAT_DEEP (128): the general walk of the
+    # baseline kernel renders them.  RTG_ERR_UNSUPPORTED is left for nesting beyond that walk's (documented) stack bounds.
+    FEAT_BOUNDARY, FEAT_DEEP, OP_BEND, OP_SAVE, OP_MERGE = 16, 128, 8, 9, 10
     iso = b.isotropic(b.constant(S.vfrom(1.0)))
     box = b.rect_prism(S.v(0, 0, 0), S.v(1, 1, 1), m)
     words, feat = b.flatten([b.constant_medium(box, 0.1, iso)])   # a boundary may be any object graph ...
-    assert (feat & 16) and words[0, 4] == len(words) - 1
+    assert (feat & FEAT_BOUNDARY) and not (feat & FEAT_DEEP) and words[0, 4] == len(words) - 1
     nested = b.constant_medium(b.and_(box, b.constant_medium(b.sphere(1.0, m), 0.1, iso)), 0.1, iso)
-    with pytest.raises(pkg.RtError) as e:                         # ... except one that itself holds a medium
-        b.flatten([nested])
+    words, feat = b.flatten([nested])                             # ... also one that itself holds a medium
+    ops = [int(w[7]) & 0xff for w in words]
+    assert (feat & FEAT_DEEP) and ops == [OP_MEDIUM, OP_PRISM, OP_MEDIUM, OP_SPHERE, OP_BEND, OP_END]
+    level = b.sphere(1.0, m)
+    for _ in range(3):                                            # 3 levels of media in media boundaries; the 4th is refused
+        level = b.constant_medium(b.and_(box, level), 0.1, iso)
+    b.flatten([level])
+    with pytest.raises(pkg.RtError) as e:
+        b.flatten([b.constant_medium(b.and_(box, b.constant_medium(b.and_(box, level), 0.1, iso)), 0.1, iso)])
     assert e.value.code == -5
+    # a medium below an And below a Bvh: SAVE / MERGE around the And's stream, its media replace like a list's
+    smoke = b.constant_medium(b.sphere(2.0, m), 0.1, iso)
+    words, feat = b.flatten([b.bvh([b.and_(b.sphere(1.0, m), smoke), b.sphere(3.0, m)])])
+    ops = [int(w[7]) & 0xff for w in words]
+    assert (feat & FEAT_DEEP) and ops.count(OP_SAVE) == 1 and ops.count(OP_MERGE) == 1
+    i_med = ops.index(OP_MEDIUM)
+    assert ops.index(OP_SAVE) < i_med < ops.index(OP_MERGE) and not (int(words[i_med, 7]) & (1 << 12))   # no F_UNDER_BVH inside the And
+    words, feat = b.flatten([b.bvh([smoke, b.sphere(3.0, m)])])   # directly below the Bvh: the scheduled kernels' compare rule
+    assert not (feat & FEAT_DEEP) and (int(words[[int(w[7]) & 0xff for w in words].index(OP_MEDIUM), 7]) & (1 << 12))
+    # wrappers: 4 levels for the scheduled kernels, 32 for the general walk
     deep = b.sphere(1.0, m)
-    for _ in range(6):
+    for i in range(33):
         deep = b.scale(S.v(1, 2, 1), deep)
+        if i + 1 in (4, 5, 32):
+            _, feat = b.flatten([deep])
+            assert bool(feat & FEAT_DEEP) == (i + 1 > 4), i
     with pytest.raises(pkg.RtError) as e:
         b.flatten([deep])
     assert e.value.code == -5

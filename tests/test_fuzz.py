@@ -9,10 +9,10 @@ N_SCENES = 48
 N_BOUNDARY_SCENES = 16
 
 
-def _build(pkg, backend, seed, nx, ny, general_boundaries=False):
+def _build(pkg, backend, seed, nx, ny, general_boundaries=False, deep_shapes=False):
     rs = np.random.RandomState(seed)
     b = backend.builder()
-    world = random_world(pkg, b, rs, general_boundaries=general_boundaries)
+    world = random_world(pkg, b, rs, general_boundaries=general_boundaries, deep_shapes=deep_shapes)
     cam = random_camera(pkg, backend, rs, nx, ny)
     return b, world, cam
 
@@ -81,3 +81,86 @@ def test_fuzz_graph_boundaries_bit_exact(pkg, gpu, oracle, seed):
     for k in ("aabb_tests", "prim_tests", "shaded_hits", "rays", "draws"):
         assert st_g[k] == st_o[k], (seed, k, st_g[k], st_o[k])
     assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns), img_o, "boundary fuzz scene %d, production variant" % seed)
+
+
+N_DEEP_SCENES = 24
+
+
+@pytest.mark.parametrize("seed", range(N_DEEP_SCENES))
+def test_fuzz_deep_shapes_flatten_on_host(pkg, seed):
+    """CPU-only: the shapes round 2 refused (a medium inside a medium's boundary, a medium below And below Bvh, 5-7 nested
+    wrappers) flatten; a program that holds one carries FEAT_DEEP, SAVE / MERGE pairs nest properly, media inside boundary
+    streams are closed streams themselves."""
+    b, world, _ = _build(pkg, pkg.load(), 9000 + seed, 24, 16, general_boundaries=True, deep_shapes=True)
+    words, feat = b.flatten(world)
+    ops = words[:, 7] & 0xff
+    assert int((ops == 9).sum()) == int((ops == 10).sum())
+    level = 0
+    for o in ops:
+        level += 1 if o == 9 else -1 if o == 10 else 0
+        assert 0 <= level <= 4
+    if (ops == 9).any():
+        assert feat & 128
+    depth = max_depth = 0
+    for o in ops:
+        depth += 1 if o == 4 else -1 if o == 5 else 0
+        max_depth = max(max_depth, depth)
+    med = np.nonzero(ops == 6)[0]
+    nested = any(np.isin(ops[m + 1:int(words[m, 4])], (6,)).any() for m in med)
+    assert bool(feat & 128) == bool((ops == 9).any() or nested or _deep_wrappers(words)), (seed, feat)
+
+
+def _deep_wrappers(words):
+    """more than 4 PUSH levels open at once, counted per stream (a boundary stream starts a fresh count)"""
+    ops = words[:, 7] & 0xff
+
+    def scan(lo, hi):
+        depth, i, deep = 0, lo, False
+        while i < hi:
+            o = ops[i]
+            if o == 4:
+                depth += 1
+                deep |= depth > 4
+            elif o == 5:
+                depth -= 1
+            elif o == 6:
+                end = int(words[i, 4])
+                deep |= scan(i + 1, end)
+                i = end
+                continue
+            i += 1
+        return deep
+    return scan(0, len(ops))
+
+
+def test_fuzz_deep_shapes_cover_all_three(pkg):
+    """the generator really draws the three shapes (else the GPU test below proves nothing)"""
+    seen = set()
+    for seed in range(N_DEEP_SCENES):
+        b, world, _ = _build(pkg, pkg.load(), 9000 + seed, 24, 16, general_boundaries=True, deep_shapes=True)
+        words, feat = b.flatten(world)
+        ops = words[:, 7] & 0xff
+        if (ops == 9).any():
+            seen.add("medium below And below Bvh")
+        if any(np.isin(ops[m + 1:int(words[m, 4])], (6,)).any() for m in np.nonzero(ops == 6)[0]):
+            seen.add("medium inside a boundary")
+        if _deep_wrappers(words):
+            seen.add("deep wrappers")
+    assert len(seen) == 3, seen
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(N_DEEP_SCENES))
+def test_fuzz_deep_shapes_bit_exact(pkg, gpu, oracle, seed):
+    """Every graph the reference's types allow renders: the three shapes the scheduled kernels do not walk go through the
+    general walk (rt_trace.h walk_deep, baseline kernel) -- bit-exact against the oracle's recursion, counters included."""
+    nx, ny, ns = 40, 24, 5
+    bg, wg, cam_g = _build(pkg, gpu, 9000 + seed, nx, ny, True, True)
+    bo, wo, cam_o = _build(pkg, oracle, 9000 + seed, nx, ny, True, True)
+    sg, so = bg.scene(wg), bo.scene(wo)
+    img_o, st_o = so.par_cast(cam_o, nx, ny, ns, stats=True)
+    img_g, st_g = sg.par_cast(cam_g, nx, ny, ns, stats=True)
+    assert_bit_equal(img_g, img_o, "deep fuzz scene %d" % seed)
+    for k in ("aabb_tests", "prim_tests", "shaded_hits", "rays", "draws"):
+        assert st_g[k] == st_o[k], (seed, k, st_g[k], st_o[k])
+    assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns), img_o, "deep fuzz scene %d, production variant" % seed)
