@@ -201,7 +201,9 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   unsigned long long t_shade = 0, t_serv = 0, t_box = 0, t_slow = 0, t_refill = 0, t_fin = 0, n_serv = 0, t_mark = 0, t_mark2 = 0;  // COUNT: s_memtime shares
 
 #define RT_REG_STACK0 1  // PUSH / POP of an outermost wrapper touch no memory (book-2: the moving sphere, the sphere cloud)
+#define RT_SAME_KIND_RUN 0  // (consecutive SPHERE / RECT records in one go: the lock-step kernel's; here the box lanes would wait: book2_bvh +1.7 %)
 #include "rt_full_ops.inc"
+#undef RT_SAME_KIND_RUN
 #undef RT_REG_STACK0
 
   for (;;) {

@@ -68,7 +68,9 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   unsigned long long t_shade = 0, t_box = 0, t_slow = 0, t_mark = 0;
 
 #define RT_REG_STACK0 0  // measured: six more live registers cost this kernel 7 % on sphere lists, Cornell's wrappers gain nothing
+#define RT_SAME_KIND_RUN 1  // consecutive SPHERE / RECT records in one go: simple_light (200 spheres) 16.0 -> 9.4 ms, Cornell 3.7 -> 3.6, smoke boxes 7.5 -> 7.15
 #include "rt_full_ops.inc"
+#undef RT_SAME_KIND_RUN
 #undef RT_REG_STACK0
 
   for (;;) {
