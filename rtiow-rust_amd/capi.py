@@ -142,7 +142,13 @@ class Backend:
         f("tonemap_device", C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p])
 
     def _fn(self, name, restype, argtypes):
-        fn = getattr(self.lib, self.prefix + name)
+        try:
+            fn = getattr(self.lib, self.prefix + name)
+        except AttributeError:   # an OLDER build of the library (RTIOW_GPU_LIB A/B runs): the call fails when it is made
+            def fn(*_a, _n=self.prefix + name):
+                raise RtError(ERR_INVALID, "%s: symbol %s is not exported by this build" % (self.path, _n))
+            setattr(self, "_" + name, fn)
+            return fn
         fn.restype = restype
         fn.argtypes = argtypes
         setattr(self, "_" + name, fn)

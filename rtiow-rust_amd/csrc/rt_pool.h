@@ -36,17 +36,25 @@ RT_DEV uint32_t lane_rank(uint64_t mask) {  // number of set bits below this lan
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+RT_DEV uint32_t fdiv(uint32_t n, const FastDiv f) {
+#ifdef RT_NO_FASTDIV
+  return n / f.d;  // (measurement switch: the plain divisions of rounds 1-2)
+#endif
+  if (f.d == 1u) return n;  // (wave-uniform)
+  const uint32_t q = __umulhi(n, f.m);
+  return (((n - q) >> 1) + q) >> f.s;
+}
+
 // work item -> pixel.  Work items enumerate this rank's tiles (tile % nranks == rank) in order, each
 // tile as 8x8 blocks, so the 64 items a wave grabs at start form one coherent 8x8 block.
-RT_DEV bool work_to_pixel(const DevParams& P, uint32_t w, uint32_t& x, uint32_t& row) {
+RT_DEV bool work_to_pixel(const DevParams& P, const PixMap& M, uint32_t w, uint32_t& x, uint32_t& row) {
   const uint32_t px_per_tile = P.tile_w * P.tile_h;
-  const uint32_t tiles_x = (P.nx + P.tile_w - 1u) / P.tile_w;
-  uint32_t k = w / px_per_tile, r = w - k * px_per_tile;
+  uint32_t k = fdiv(w, M.d_px_per_tile), r = w - k * px_per_tile;
   uint32_t tile = P.rank + k * P.nranks;
-  uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+  uint32_t ty = fdiv(tile, M.d_tiles_x), tx = tile - ty * M.tiles_x;
   uint32_t blocks_x = P.tile_w >> 3;
   uint32_t b = r >> 6, l = r & 63u;
-  uint32_t bx = b % blocks_x, by = b / blocks_x;
+  uint32_t by = fdiv(b, M.d_blocks_x), bx = b - by * blocks_x;
   x = tx * P.tile_w + bx * 8u + (l & 7u);
   row = ty * P.tile_h + by * 8u + (l >> 3);
   return x < P.nx && row < P.ny;
@@ -214,10 +222,9 @@ typedef float f32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
 #endif
 
 // inverse of work_to_pixel
-RT_DEV uint32_t pixel_to_work(const DevParams& P, uint32_t x, uint32_t row) {
-  const uint32_t tiles_x = (P.nx + P.tile_w - 1u) / P.tile_w;
-  uint32_t tx = x / P.tile_w, ty = row / P.tile_h;
-  uint32_t k = (ty * tiles_x + tx) / P.nranks;  // this rank's k-th tile
+RT_DEV uint32_t pixel_to_work(const DevParams& P, const PixMap& M, uint32_t x, uint32_t row) {
+  uint32_t tx = fdiv(x, M.d_tile_w), ty = fdiv(row, M.d_tile_h);
+  uint32_t k = fdiv(ty * M.tiles_x + tx, M.d_nranks);  // this rank's k-th tile
   uint32_t lx = x - tx * P.tile_w, ly = row - ty * P.tile_h;
   uint32_t b = (ly >> 3) * (P.tile_w >> 3) + (lx >> 3);
   return k * (P.tile_w * P.tile_h) + b * 64u + (ly & 7u) * 8u + (lx & 7u);
@@ -232,6 +239,7 @@ struct LaunchConsts {
   DevCamera cam;
   DevParams P;
   ChunkMode cm;
+  PixMap pm;
 };
 typedef const __attribute__((address_space(4))) uint32_t* const_u32_ptr;
 template <typename T>
@@ -254,11 +262,11 @@ __global__ void write_lpt_descriptor(LptQueue* dst, LptQueue v) { *dst = v; }
 // [cm.s_begin, P.ns) of this pass are added IN ORDER to the running sum of the earlier passes -- (0, 0, 0) for the first
 // pass (vec3.rs:197), else what the previous pass left in the framebuffer, the same f32 bits the sequential fold would hold
 // at that point -- and the last pass divides by the frame's sample count `ns_frame` (lib.rs:374).
-__global__ void fold_samples_kernel(DevParams P, ChunkMode cm, float* __restrict__ out, uint32_t ns_frame) {
+__global__ void fold_samples_kernel(DevParams P, ChunkMode cm, PixMap pm, float* __restrict__ out, uint32_t ns_frame) {
   uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= cm.pix_work) return;
   uint32_t x, row;
-  if (!work_to_pixel(P, w, x, row)) return;
+  if (!work_to_pixel(P, pm, w, x, row)) return;
   float* o = out + 3ull * ((size_t)row * P.nx + x);
   V3 col = mk(0.f, 0.f, 0.f);
   if (cm.s_begin != 0u) col = mk(o[0], o[1], o[2]);
@@ -499,7 +507,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
     if (tr_out) tr_slot = reinterpret_cast<uint32_t*>(counters[31]) + ((size_t)blockIdx.x * n_waves + wave) * (POOL * 3u);
   }
   uint32_t n_box_it = 0, n_box_lanes = 0, n_sph_it = 0, n_sph_lanes = 0, n_shade = 0, n_shade_lanes = 0, n_refill = 0;
-  uint32_t n_end = 0, n_end_lanes = 0;
+  uint32_t n_end = 0, n_end_lanes = 0, n_refill_lanes = 0;
   unsigned long long t_shade = 0, t_serv = 0, t_box = 0, t_sph = 0, t_mark = 0, t_mark2 = 0;  // COUNT: s_memtime shares
 
   // load the record at pc into (cx, cy, cz, c_skip, c_flags)
@@ -705,7 +713,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           if (COUNT) total_draws += rng.draws;
           if (COUNT && tr_slot) tr_slot[j] += rng.draws;
           lpt_on = s < cm.lpt_samples && bounces == cm.lpt_deep;  // phase 1 of the cost-ordered queue: a deep scatter event
-          if (lpt_on) lpt_blk = pixel_to_work(P, xy & 0xffffu, xy >> 16) >> 8;
+          if (lpt_on) lpt_blk = pixel_to_work(P, load_const(&lc->pm), xy & 0xffffu, xy >> 16) >> 8;
           if (scattered) {
             strength = vmul(strength, att);  // lib.rs:87
             if (bounces != P.max_bounces) {  // lib.rs:93-97
@@ -766,10 +774,10 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
               }
             }
             if (cm.scratch) {  // chunk mode: park the sample colour, folded in order afterwards
-              float* sp = cm.scratch + 3ull * ((size_t)s * cm.pix_work + pixel_to_work(P, x, row));
+              float* sp = cm.scratch + 3ull * ((size_t)s * cm.pix_work + pixel_to_work(P, load_const(&lc->pm), x, row));
               RT_SCRATCH_STORE(sp, result);
               if (COUNT && tr_out) {
-                uint32_t* tp = tr_out + 4ull * ((size_t)s * cm.pix_work + pixel_to_work(P, x, row));
+                uint32_t* tp = tr_out + 4ull * ((size_t)s * cm.pix_work + pixel_to_work(P, load_const(&lc->pm), x, row));
                 tp[0] = SLOT_U(PF_BOUNCES, j), tp[1] = tr_slot[j], tp[2] = tr_slot[POOL + j], tp[3] = tr_slot[2u * POOL + j];
               }
             } else {
@@ -816,7 +824,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
                 w += w_delta;
                 first = cm.s_begin + w_chunk * cm.chunk;
               }
-              if (work_to_pixel(P, w, x, row) && first < P.ns) {
+              if (work_to_pixel(P, load_const(&lc->pm), w, x, row) && first < P.ns) {
                 s = first;
                 col = mk(0.f, 0.f, 0.f);
                 st = ST_GEN;
@@ -877,7 +885,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
             have_ray = true;
           }
           t_count -= got;
-          if (COUNT) n_refill++;
+          if (COUNT) n_refill++, n_refill_lanes += got;
         }
       }
       if (COUNT) t_serv += RT_TICK() - t_mark;
@@ -959,7 +967,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
       atomicAdd(&sched[0], (unsigned long long)n_box_it), atomicAdd(&sched[1], (unsigned long long)n_box_lanes);
       atomicAdd(&sched[2], (unsigned long long)n_sph_it), atomicAdd(&sched[3], (unsigned long long)n_sph_lanes);
       atomicAdd(&sched[4], (unsigned long long)n_shade), atomicAdd(&sched[5], (unsigned long long)n_shade_lanes);
-      atomicAdd(&sched[6], (unsigned long long)n_refill);
+      atomicAdd(&sched[6], (unsigned long long)n_refill), atomicAdd(&sched[7], (unsigned long long)n_refill_lanes);
       atomicAdd(&counters[16], t_shade), atomicAdd(&counters[17], t_serv - t_shade), atomicAdd(&counters[18], t_box),
           atomicAdd(&counters[19], t_sph);
       atomicAdd(&counters[20], (unsigned long long)n_end), atomicAdd(&counters[21], (unsigned long long)n_end_lanes);

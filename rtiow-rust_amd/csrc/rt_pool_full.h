@@ -338,16 +338,16 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           if (COUNT) trd += rng.draws;
           live = !ended;
           if (ended) {
-            float* sp = cm.scratch + 3ull * ((size_t)s * cm.pix_work + pixel_to_work(P, x, row));
+            float* sp = cm.scratch + 3ull * ((size_t)s * cm.pix_work + pixel_to_work(P, load_const(&lc->pm), x, row));
             RT_SCRATCH_STORE(sp, result);
             if (COUNT && tr_out) {
-              uint32_t* tp = tr_out + 4ull * ((size_t)s * cm.pix_work + pixel_to_work(P, x, row));
+              uint32_t* tp = tr_out + 4ull * ((size_t)s * cm.pix_work + pixel_to_work(P, load_const(&lc->pm), x, row));
               tp[0] = bounces, tp[1] = trd, tp[2] = tra, tp[3] = trp;
             }
             s++;
           }
         }
-        if (cm.lpt_samples) lpt_count(cm, lpt_on, lpt_on ? pixel_to_work(P, x, row) >> 8 : 0u);
+        if (cm.lpt_samples) lpt_count(cm, lpt_on, lpt_on ? pixel_to_work(P, load_const(&lc->pm), x, row) >> 8 : 0u);
         const uint64_t m_live = __builtin_amdgcn_ballot_w64(live), m_end = __builtin_amdgcn_ballot_w64(ended);
         if (live) {  // push onto T
           const uint32_t i = t_count + lane_rank(m_live);
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
               uint32_t w = w_next + r;
               w += w_delta;
               const uint32_t first = cm.s_begin + w_chunk * cm.chunk;
-              if (work_to_pixel(P, w, x, row) && first < P.ns) {
+              if (work_to_pixel(P, load_const(&lc->pm), w, x, row) && first < P.ns) {
                 s = first;
                 st = ST_GEN;
               }

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         }
         if (COUNT) total_draws += rng.draws, tr_draws += rng.draws;
         if (ended) {
-          const size_t at = (size_t)ps * cm.pix_work + pixel_to_work(P, px, prow);
+          const size_t at = (size_t)ps * cm.pix_work + pixel_to_work(P, load_const(&lc->pm), px, prow);
           RT_SCRATCH_STORE(cm.scratch + 3ull * at, result);
           if (COUNT && tr_out) {
             uint32_t* tp = tr_out + 4ull * at;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           st = ST_TRAV;
         }
       }
-      if (cm.lpt_samples) lpt_count(cm, lpt_on, lpt_on ? pixel_to_work(P, px, prow) >> 8 : 0u);
+      if (cm.lpt_samples) lpt_count(cm, lpt_on, lpt_on ? pixel_to_work(P, load_const(&lc->pm), px, prow) >> 8 : 0u);
       for (;;) {  // next work item (rt_pool.h)
         const uint64_t need = __builtin_amdgcn_ballot_w64(st == ST_NEED_PIXEL);
         if (need == 0) break;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           if (r < avail) {
             const uint32_t w = w_next + r + w_delta;
             const uint32_t first = cm.s_begin + w_chunk * cm.chunk;
-            if (work_to_pixel(P, w, px, prow) && first < P.ns) {
+            if (work_to_pixel(P, load_const(&lc->pm), w, px, prow) && first < P.ns) {
               ps = first;
               st = ST_GEN;
             }

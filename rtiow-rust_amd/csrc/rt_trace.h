@@ -25,12 +25,50 @@ struct DevCamera {  // camera.rs:6-15
   float lens_radius, e0, e1;
 };
 
+// n / d for a divisor that is fixed for the launch: libdivide's branch-free form, q = mulhi(n, m); (((n - q) >> 1) + q) >> s --
+// exact for every 32-bit n (d >= 2; power of two: m = 0, s = log2 d - 1; d = 1 passes n through).  A 32-bit division costs ~25
+// VALU instructions on gfx950; the work-item <-> pixel maps of the pool kernels do eight of them per sample.
+struct FastDiv {
+  uint32_t d, m, s;
+};
+inline FastDiv make_fastdiv(uint32_t d) {  // host
+  FastDiv f{d, 0u, 0u};
+  if (d < 2u) return f;
+  uint32_t fl = 31u;
+  while (!(d >> fl)) fl--;
+  if ((d & (d - 1u)) == 0u) {
+    f.s = fl - 1u;
+    return f;
+  }
+  const uint64_t num = 1ull << (32u + fl);
+  uint64_t pm = num / d;
+  const uint64_t rem = num % d;
+  pm *= 2u;
+  if (rem * 2u >= d) pm += 1u;
+  f.m = (uint32_t)(pm + 1u), f.s = fl;
+  return f;
+}
+
 struct DevParams {
   uint32_t nx, ny, ns, max_bounces;
   float t_near;
   uint32_t seed_lo, seed_hi;
   uint32_t tile_w, tile_h, rank, nranks;
 };
+// derived from DevParams (make_pixmap): tiles per row and the divisors of the work-item <-> pixel maps (rt_pool.h).  Its own
+// struct in the launch constants, read field by field where a map is evaluated: inside DevParams every pass that loads the
+// frame parameters paid for 19 more SGPRs (C2 +0.5 %).
+struct PixMap {
+  uint32_t tiles_x;
+  FastDiv d_tile_w, d_tile_h, d_tiles_x, d_nranks, d_px_per_tile, d_blocks_x;
+};
+inline PixMap make_pixmap(const DevParams& d) {  // host
+  PixMap m;
+  m.tiles_x = (d.nx + d.tile_w - 1u) / d.tile_w;
+  m.d_tile_w = make_fastdiv(d.tile_w), m.d_tile_h = make_fastdiv(d.tile_h), m.d_tiles_x = make_fastdiv(m.tiles_x);
+  m.d_nranks = make_fastdiv(d.nranks), m.d_px_per_tile = make_fastdiv(d.tile_w * d.tile_h), m.d_blocks_x = make_fastdiv(d.tile_w >> 3);
+  return m;
+}
 
 struct HitRec {  // object.rs:61-71
   float t;

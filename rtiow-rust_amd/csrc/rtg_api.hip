@@ -311,13 +311,13 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
               s0, dp.ns, d.ns, grid, bt, per_cu, lds, (int)use_lds, (int)ray_lds, cm.n_chunks, cm.chunk, (cm.lpt_samples - (cm.lpt_samples ? s0 : 0u)) / (cm.chunk ? cm.chunk : 1u));
     e = grow((void**)&s->d_slots, &s->slots_bytes, (size_t)grid * waves * POOL * POOL_FIELDS * sizeof(uint32_t));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(write_launch_consts, dim3(1), dim3(1), 0, stream, s->d_consts, LaunchConsts{cam, dp, cm});
+    hipLaunchKernelGGL(write_launch_consts, dim3(1), dim3(1), 0, stream, s->d_consts, LaunchConsts{cam, dp, cm, make_pixmap(dp)});
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(bt), lds, stream, dev, (const LaunchConsts*)s->d_consts, d_out, (uint32_t)total_work, queue,
                        s->d_counters, s->pool_tune, s->d_slots);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (cm.scratch) {
-      hipLaunchKernelGGL(fold_samples_kernel, dim3((uint32_t)((pix_work + 255) / 256)), dim3(256), 0, stream, dp, cm, d_out, d.ns);
+      hipLaunchKernelGGL(fold_samples_kernel, dim3((uint32_t)((pix_work + 255) / 256)), dim3(256), 0, stream, dp, cm, make_pixmap(dp), d_out, d.ns);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
     }
@@ -510,7 +510,7 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
     if (s->verbose)
       fprintf(stderr, "[rtg] full pool: samples [%u, %u) of %u: grid %u x %d threads, %d WG/CU, lds %zu B (program window: %u of %u records), cost-ordered queue after %u chunk(s)\n",
               s0, dp.ns, d.ns, grid, bt, per_cu, lds, window, s->n_prog, cm.lpt_samples - (cm.lpt_samples ? s0 : 0u));
-    hipLaunchKernelGGL(write_launch_consts, dim3(1), dim3(1), 0, stream, s->d_consts, LaunchConsts{cam, dp, cm});
+    hipLaunchKernelGGL(write_launch_consts, dim3(1), dim3(1), 0, stream, s->d_consts, LaunchConsts{cam, dp, cm, make_pixmap(dp)});
     if (lock_step)
       hipLaunchKernelGGL(k2, dim3(grid), dim3(bt), lds2, stream, s->dev, (const LaunchConsts*)s->d_consts, d_out, (uint32_t)total_work, queue,
                          s->d_counters, s->sync_tune, s->d_stack, window);
@@ -519,7 +519,7 @@ static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const Dev
                          s->d_counters, s->full_tune, s->d_slots, s->d_stack, window);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fold_samples_kernel, dim3((uint32_t)((pix_work + 255) / 256)), dim3(256), 0, stream, dp, cm, d_out, d.ns);
+    hipLaunchKernelGGL(fold_samples_kernel, dim3((uint32_t)((pix_work + 255) / 256)), dim3(256), 0, stream, dp, cm, make_pixmap(dp), d_out, d.ns);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -1054,8 +1054,9 @@ int rtg_par_cast_device(rtg_scene* s, const rtg_camera* camera, const rtg_params
                 100 * f[1] / tt, f[0] ? (double)f[1] / f[0] : 0., 100 * q[15] / tt, q[6] ? (double)q[15] / q[6] : 0.);
       }
       fprintf(stderr, "[rtg] pool schedule: box steps %llu (avg %.1f lanes), sphere passes %llu (avg %.1f lanes), shade passes %llu "
-                "(avg %.1f lanes), end / camera-ray passes %llu (avg %.1f lanes), refills %llu\n", q[0], q[0] ? (double)q[1] / q[0] : 0.0, q[2],
-                q[2] ? (double)q[3] / q[2] : 0.0, q[4], q[4] ? (double)q[5] / q[4] : 0.0, q[12], q[12] ? (double)q[13] / q[12] : 0.0, q[6]);
+                "(avg %.1f lanes), end / camera-ray passes %llu (avg %.1f lanes), refills %llu (avg %.1f lanes)\n", q[0], q[0] ? (double)q[1] / q[0] : 0.0, q[2],
+                q[2] ? (double)q[3] / q[2] : 0.0, q[4], q[4] ? (double)q[5] / q[4] : 0.0, q[12], q[12] ? (double)q[13] / q[12] : 0.0, q[6],
+                q[6] && q[7] ? (double)q[7] / q[6] : 0.0);
     }
   }
   return RTG_OK;
