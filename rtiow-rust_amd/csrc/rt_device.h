@@ -139,6 +139,20 @@ RT_DEV V3 in_unit_sphere(SampleRng& rng) {
     if (vdot(v, v) < 1.f) return v;
   }
 }
+// the same loop cut off after `max_tries` attempts: false = no direction yet, the stream stands behind the last attempt
+RT_DEV bool in_unit_sphere_tries(SampleRng& rng, uint32_t max_tries, V3& out) {
+  for (uint32_t k = 0; k < max_tries; k++) {
+    float a = rng.gen_f32();
+    float b = rng.gen_f32();
+    float c = rng.gen_f32();
+    V3 v = vsub(smul(2.f, mk(a, b, c)), splat(1.f));
+    if (vdot(v, v) < 1.f) {
+      out = v;
+      return true;
+    }
+  }
+  return false;
+}
 // vec3.rs:32-39
 RT_DEV V3 in_unit_disc(SampleRng& rng) {
   for (;;) {

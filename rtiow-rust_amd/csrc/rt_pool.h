@@ -362,6 +362,9 @@ RT_DEV uint4 fetch_hi_global(const DevScene& sc, uint32_t idx) {  // pc-scaled s
   return h;
 }
 
+#ifndef RT_SCATTER_TRIES
+#define RT_SCATTER_TRIES 4  // in_unit_sphere attempts per SCATTER pass and slot (0 = as many as the unluckiest lane needs)
+#endif
 #ifndef RT_POOL_MAX_THREADS
 #define RT_POOL_MAX_THREADS 1024
 #endif
@@ -466,6 +469,19 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
     const uint32_t v = lds_bpc[j];
     if (!USE_LDS) return v;
     return v >= (SLOT_ENDED & 0xffffu) ? (v | 0xffff0000u) : pc0 + (v << 3);
+  };
+  // S-list entries (hits on scattering materials: always a record, never a marker) carry in the two top bits of best_pc how
+  // many SCATTER passes have already tried to draw their in_unit_sphere (RT_SCATTER_TRIES attempts each, see the pass)
+  constexpr uint32_t BPC_TRY_SHIFT = (BEST_LDS && USE_LDS) ? 14u : 30u;  // (16-bit form: image offsets / 8 < 2^14, i.e. images < 128 KB: LDS holds no larger one)
+  auto get_bpc_tries = [&](uint32_t j, uint32_t& tries) -> uint32_t {
+    uint32_t v = BEST_LDS ? (uint32_t)lds_bpc[j] : slot[PF_BEST_PC * POOL + j];
+    tries = v >> BPC_TRY_SHIFT;
+    v &= (1u << BPC_TRY_SHIFT) - 1u;
+    return (BEST_LDS && USE_LDS) ? pc0 + (v << 3) : v;
+  };
+  auto bump_bpc_tries = [&](uint32_t j) {
+    if (BEST_LDS) lds_bpc[j] = (bpc_t)(lds_bpc[j] + (bpc_t)(1u << BPC_TRY_SHIFT));
+    else slot[PF_BEST_PC * POOL + j] += 1u << BPC_TRY_SHIFT;
   };
   // all slots start as "need a work item", all on the E-list
   for (uint32_t j = lane; j < POOL; j += 64u) {
@@ -634,11 +650,12 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
         const DevParams P = load_const(&lc->P);
         const ChunkMode cm = load_const(&lc->cm);
         const uint64_t seed = ((uint64_t)P.seed_hi << 32) | P.seed_lo;
-        bool live = false, ended = false, lpt_on = false;
+        bool live = false, ended = false, lpt_on = false, deferred = false;
         uint32_t j = 0, lpt_blk = 0;
         if (lane < take) {
           j = slist[s_count + lane];
-          const uint32_t bpc = get_bpc(j);
+          uint32_t tries;
+          const uint32_t bpc = get_bpc_tries(j, tries);
           V3 so = mk(RAY_F(PF_O, j), RAY_F(PF_O + 1, j), RAY_F(PF_O + 2, j));
           V3 sd = mk(RAY_F(PF_D, j), RAY_F(PF_D + 1, j), RAY_F(PF_D + 2, j));
           uint32_t bounces = SLOT_U(PF_BOUNCES, j);
@@ -651,7 +668,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           SampleRng rng;
           rng.init(seed, (P.ny - 1u - (xy >> 16)) * P.nx + (xy & 0xffffu), s);
           rng.set_event(bounces + 1u);
-          if (COUNT) cnt.shaded++;
+          rng.seek(3u * RT_SCATTER_TRIES * tries);  // the attempts earlier passes made (whole Philox blocks: no block is generated here)
           const uint4 plo = RT_SPHERE_GEOM(bpc);
           const uint32_t pflags = RT_SPHERE_FLAGS(bpc);
           V3 off = mk(u2f(plo.x), u2f(plo.y), u2f(plo.z));
@@ -670,8 +687,15 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           bool scattered = true;
           // Lambertian, Metal and Isotropic each draw exactly one in_unit_sphere before any other draw of
           // this event (reflect() consumes no randomness): ONE rejection loop serves all three.
+          // The rejection loop runs in lock-step: the wave pays for the UNLUCKIEST of its 64 lanes (6.9 attempts expected,
+          // against 1.9 for one lane; an attempt is three draws, a Philox block four).  So a pass makes at most
+          // RT_SCATTER_TRIES = 4 attempts (12 draws = 3 whole blocks: every lane crosses the block boundaries at the same
+          // draws); the 5 % of the lanes that are still without a direction leave their slot as it is, note the try in
+          // best_pc and go back on the S-list -- a later pass continues their stream where this one stopped (same draws, same
+          // order: the stream is counter-based).  The fourth pass of a slot loops to the end.
           V3 rs = mk(0.f, 0.f, 0.f);
-          if (kind != MAT_DIELECTRIC) rs = in_unit_sphere(rng);
+          if (kind != MAT_DIELECTRIC) deferred = !in_unit_sphere_tries(rng, (RT_SCATTER_TRIES && tries < 3u) ? (uint32_t)RT_SCATTER_TRIES : 0xffffffffu, rs);
+          if (COUNT && !deferred) cnt.shaded++;
           // |d| and unit(d) once for the Metal and the Dielectric lanes of the pass (vec3.rs:59,66): the two
           // branches below are exclusive, the wave usually runs both, and a sqrt + three divides is what they share
           float sd_len = 0.f;
@@ -712,16 +736,19 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           }
           if (COUNT) total_draws += rng.draws;
           if (COUNT && tr_slot) tr_slot[j] += rng.draws;
-          lpt_on = s < cm.lpt_samples && bounces == cm.lpt_deep;  // phase 1 of the cost-ordered queue: a deep scatter event
+          lpt_on = !deferred && s < cm.lpt_samples && bounces == cm.lpt_deep;  // phase 1 of the cost-ordered queue: a deep scatter event
           if (lpt_on) lpt_blk = pixel_to_work(P, load_const(&lc->pm), xy & 0xffffu, xy >> 16) >> 8;
-          if (scattered) {
+          if (deferred) {
+            bump_bpc_tries(j);
+          } else if (scattered) {
             strength = vmul(strength, att);  // lib.rs:87
             if (bounces != P.max_bounces) {  // lib.rs:93-97
               bounces += 1;
               live = true;
             }
           }
-          if (live) {
+          if (deferred) {
+          } else if (live) {
             RAY_F(PF_O, j) = hp.x, RAY_F(PF_O + 1, j) = hp.y, RAY_F(PF_O + 2, j) = hp.z;
             RAY_F(PF_D, j) = nd.x, RAY_F(PF_D + 1, j) = nd.y, RAY_F(PF_D + 2, j) = nd.z;
             SLOT_F(PF_STRENGTH, j) = strength.x, SLOT_F(PF_STRENGTH + 1, j) = strength.y, SLOT_F(PF_STRENGTH + 2, j) = strength.z;
@@ -734,10 +761,13 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
         }
         if (cm.lpt_samples) lpt_count(cm, lpt_on, lpt_blk);
         const uint64_t m_live = __builtin_amdgcn_ballot_w64(live), m_ended = __builtin_amdgcn_ballot_w64(ended);
+        const uint64_t m_def = __builtin_amdgcn_ballot_w64(deferred);
         if (live) tlist[t_count + lane_rank(m_live)] = (uint16_t)j;
         if (ended) elist[e_count + lane_rank(m_ended)] = (uint16_t)j;
+        if (deferred) slist[s_count + lane_rank(m_def)] = (uint16_t)j;  // (over entries this pass has already read)
         t_count += (uint32_t)__builtin_popcountll(m_live);
         e_count += (uint32_t)__builtin_popcountll(m_ended);
+        s_count += (uint32_t)__builtin_popcountll(m_def);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         if (COUNT) t_shade += RT_TICK() - t_mark2;
       }

@@ -245,14 +245,16 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         V3 accum = so;
         float stime = 0.f;
         uint32_t bounces = 0, s = 0, x = 0, row = 0;
-        bool lpt_on = false, live = false, ended = false;
+        bool lpt_on = false, live = false, ended = false, deferred = false;
+        uint32_t hm = NO_HIT, ev_next = 0;
+        V3 p = so, n = so, sd0 = so;
         if (lane < take) {
           const uint32_t j = q0 + count + lane;  // pop: the top `take` entries
-          const uint32_t hm = SQ_LD_U(SQ_HITMAT, j);
+          hm = SQ_LD_U(SQ_HITMAT, j);
           // The texture value is fetched FIRST, while almost nothing of this pass is live: texture_eval
           // (Perlin turbulence / checker) is an out-of-line call and everything live across it adds to
           // the kernel's register count.
-          const V3 p = mk(SQ_LD_F(SQ_P, j), SQ_LD_F(SQ_P + 1, j), SQ_LD_F(SQ_P + 2, j));
+          p = mk(SQ_LD_F(SQ_P, j), SQ_LD_F(SQ_P + 1, j), SQ_LD_F(SQ_P + 2, j));
           uint4 mlo = make_uint4(0, 0, 0, 0), mhi = make_uint4(0, 0, 0, 0);
           V3 texval = mk(0.f, 0.f, 0.f);
           if (hm != NO_HIT) {
@@ -269,12 +271,15 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           SampleRng rng;
           rng.init(seed, (P.ny - 1u - row) * P.nx + x, s);
           rng.set_event(bounces + 1u);
-          rng.seek(SQ_LD_U(SQ_EVDRAWS, j));  // continue after the medium draws of this event's traversal
+          // continue after the medium draws of this event's traversal -- and after the attempts earlier passes made for this ray
+          // (bits 28-31: how many passes tried; rt_pool.h RT_SCATTER_TRIES)
+          const uint32_t evw = SQ_LD_U(SQ_EVDRAWS, j), tries = evw >> 28;
+          rng.seek(evw & 0x0fffffffu);
+          sd0 = sd;
           ended = true;
           V3 result = mk(0.f, 0.f, 0.f);
           if (hm != NO_HIT) {
-            if (COUNT) cnt.shaded++;
-            const V3 n = mk(SQ_LD_F(SQ_N, j), SQ_LD_F(SQ_N + 1, j), SQ_LD_F(SQ_N + 2, j));
+            n = mk(SQ_LD_F(SQ_N, j), SQ_LD_F(SQ_N + 1, j), SQ_LD_F(SQ_N + 2, j));
             const uint32_t kind = mhi.w & 0xffu;
             const float param = u2f(mlo.w);
             V3 emitted = mk(0.f, 0.f, 0.f);
@@ -283,7 +288,9 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
             V3 nd = mk(0.f, 0.f, 0.f), att = texval;  // Lambertian / Isotropic: albedo(p)
             bool scattered = true;
             V3 rs = mk(0.f, 0.f, 0.f);
-            if (kind == MAT_LAMBERTIAN || kind == MAT_METAL || kind == MAT_ISOTROPIC) rs = in_unit_sphere(rng);
+            if (kind == MAT_LAMBERTIAN || kind == MAT_METAL || kind == MAT_ISOTROPIC)
+              deferred = !in_unit_sphere_tries(rng, (RT_SCATTER_TRIES && tries < 3u) ? (uint32_t)RT_SCATTER_TRIES : 0xffffffffu, rs);
+            if (COUNT && !deferred) cnt.shaded++;
             float sd_len = 0.f;  // |d| and unit(d) once for the Metal and the Dielectric lanes (rt_pool.h)
             V3 sd_unit = sd;
             if (kind == MAT_METAL || kind == MAT_DIELECTRIC) sd_len = vlen(sd), sd_unit = sdiv(sd, sd_len);
@@ -324,7 +331,10 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
               nd = rs;
             }
             result = accum;
-            if (scattered) {
+            if (deferred) {  // no direction yet: the ray goes back on its stack as it came, the stream position noted (rt_pool.h)
+              ended = false;
+              ev_next = ((evw & 0x0fffffffu) + rng.draws) | ((tries + 1u) << 28);
+            } else if (scattered) {
               so = p, sd = nd;  // time is carried over by every material
               strength = vmul(strength, att);
               if (bounces != P.max_bounces) {
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           }
           if (COUNT) total_draws += rng.draws;
           if (COUNT) trd += rng.draws;
-          live = !ended;
+          live = !ended && !deferred;
           if (ended) {
             float* sp = cm.scratch + 3ull * ((size_t)s * cm.pix_work + pixel_to_work(P, load_const(&lc->pm), x, row));
             RT_SCRATCH_STORE(sp, result);
@@ -367,6 +377,22 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         }
         t_count += (uint32_t)__builtin_popcountll(m_live);
         n_count += (uint32_t)__builtin_popcountll(m_end);
+        const uint64_t m_def = __builtin_amdgcn_ballot_w64(deferred);
+        if (m_def != 0) {  // back onto the stack they came from, over entries this pass has consumed
+          if (deferred) {
+            const uint32_t i = q0 + count + lane_rank(m_def);
+            SQ_ST_U(SQ_HITMAT, i, hm);
+            SQ_ST_F(SQ_P, i, p.x), SQ_ST_F(SQ_P + 1, i, p.y), SQ_ST_F(SQ_P + 2, i, p.z);
+            SQ_ST_F(SQ_N, i, n.x), SQ_ST_F(SQ_N + 1, i, n.y), SQ_ST_F(SQ_N + 2, i, n.z);
+            SQ_ST_F(SQ_D, i, sd0.x), SQ_ST_F(SQ_D + 1, i, sd0.y), SQ_ST_F(SQ_D + 2, i, sd0.z);
+            SQ_ST_F(SQ_TIME, i, stime);
+            SQ_ST_U(SQ_EVDRAWS, i, ev_next);
+            SQ_ST_F(SQ_STRENGTH, i, strength.x), SQ_ST_F(SQ_STRENGTH + 1, i, strength.y), SQ_ST_F(SQ_STRENGTH + 2, i, strength.z);
+            SQ_ST_U(SQ_BOUNCES, i, bounces), SQ_ST_U(SQ_SAMPLE, i, s), SQ_ST_U(SQ_XY, i, x | (row << 16));
+            if (COUNT && tr_out) SQ_ST_U(SQ_TRACE, i, trd), SQ_ST_U(SQ_TRACE + 1, i, tra), SQ_ST_U(SQ_TRACE + 2, i, trp);
+          }
+          count += (uint32_t)__builtin_popcountll(m_def);
+        }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         if (COUNT) t_shade += RT_TICK() - t_mark2;
       };
