@@ -273,7 +273,8 @@ static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParam
   if (wide) dev.lds_off = (const uint32_t*)s->buffers[7], dev.lds_image_bytes = s->wide_bytes;  // the WIDE kernel's reading of these two
   bool use_lds = image != 0 && pool_lds_bytes(image, s->n_mat, waves, true, false) <= lds_limit;
   if (wide && !use_lds) return hipErrorNotSupported;  // (rtg_scene_set_option refuses bvh4 for images that do not fit)
-  bool ray_lds = s->ray_lds && pool_lds_bytes(image, s->n_mat, waves, use_lds, true) <= lds_limit;
+  // (hot slot fields in LDS keep best_pc as 16 bits = 14 bits of image offset / 8 + 2 bits of scatter tries: images < 128 KB)
+  bool ray_lds = s->ray_lds && pool_lds_bytes(image, s->n_mat, waves, use_lds, true) <= lds_limit && (!use_lds || image < (1u << 17));
   size_t lds = pool_lds_bytes(image, s->n_mat, waves, use_lds, ray_lds);
   void (*kernel)(DevScene, const LaunchConsts*, float*, uint32_t, uint32_t*, unsigned long long*, PoolTuning, uint32_t*);
   if (wide) kernel = ray_lds ? render_lean_pool<true, COUNT, true, true> : render_lean_pool<true, COUNT, false, true>;
