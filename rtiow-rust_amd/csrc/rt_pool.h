@@ -135,7 +135,7 @@ struct ChunkMode {
   // Sample passes (bounded scratch): a launch renders the samples [s_begin, P.ns) of every pixel -- P.ns of the LAUNCH is
   // the end of its pass, not the frame's sample count -- and `scratch` is biased so that sample s of pixel work index w
   // still sits at scratch[3 * (s * pix_work + w)].  One pass (s_begin = 0, P.ns = ns) unless the frame's per-sample
-  // colours exceed the scratch budget (rtg_api.hip render_passes); the fold kernel carries the running per-pixel sum
+  // colours exceed the scratch budget (rtg_launch.inc samples_per_pass); the fold kernel carries the running per-pixel sum
   // from pass to pass in the framebuffer itself, so the fold stays the reference's left fold (lib.rs:365-374).
   uint32_t s_begin;
 };
@@ -302,7 +302,7 @@ struct PoolTuning {
 // ds_read2_b32 an unaligned pair needs); the offset is fixed per ray, so the swap costs no instruction per step.
 constexpr uint32_t LDS_BOX_BYTES = 56, LDS_SPHERE_BYTES = 24, LDS_END_BYTES = 8 + 56;
 constexpr uint32_t LDS_BOX_BIT = 0x80000000u;
-// 4-wide image (template parameter WIDE, option `bvh4`; built by rtg_api.hip build_wide_image; offsets relative to the image):
+// 4-wide image (template parameter WIDE, option `bvh4`; built by rtg_launch.inc build_wide_image; offsets relative to the image):
 //   NODE   208 B  dw0 parent node (WIDE_NO_PARENT: the root)   dw1 LDS_BOX_BIT | OP_BOX | level << 8 | children << 12 | leaf mask << 16
 //                 dw2-3 four child offsets / 8 (u16 each)       dw4-51 four boxes, each as the BOX record above: the three
 //                 (min, max) pairs, then the three (max, min) pairs (a lane reads ITS pair per axis with one ds_read_b64)

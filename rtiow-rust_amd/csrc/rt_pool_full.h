@@ -20,7 +20,7 @@
 //    during traversal travels with the path so that Material::scatter continues the stream where
 //    traversal left it (draw order of SURVEY 8a);
 //  * always one sample per work item + ordered fold (frames whose sample colours exceed the scratch budget are rendered
-//    in several sample passes: rtg_api.hip samples_per_pass).
+//    in several sample passes: rtg_launch.inc samples_per_pass).
 #pragma once
 #include "rt_pool.h"
 

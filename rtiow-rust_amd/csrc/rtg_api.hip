@@ -26,107 +26,7 @@
 
 using namespace rtg;
 
-// ===================================================================================================
-// Kernels
-// ===================================================================================================
-constexpr uint32_t FEAT_ALL = FEAT_XFORM | FEAT_MEDIUM | FEAT_RECT | FEAT_TEXTURE;
-
-__device__ __forceinline__ void flush_counts(const Counts& c, uint32_t draws, unsigned long long* g) {
-  // one atomic per counter per wave would be nicer; the instrumented variant is not the timed one
-  atomicAdd(&g[0], (unsigned long long)c.aabb);
-  atomicAdd(&g[1], (unsigned long long)c.prim);
-  atomicAdd(&g[2], (unsigned long long)c.shaded);
-  atomicAdd(&g[3], (unsigned long long)c.rays);
-  atomicAdd(&g[4], (unsigned long long)draws);
-}
-
-// par_cast (lib.rs:363-376): one lane owns one pixel and folds its ns samples IN ORDER
-// (iter::Sum is a left fold from (0,0,0), vec3.rs:195-203), then divides by ns.
-// Block = 16x16 pixels, each wave an 8x8 sub-tile (primary rays of a wave stay coherent).
-template <uint32_t FEAT, bool COUNT>
-__global__ __launch_bounds__(256) void render_kernel(DevScene sc, DevCamera cam, DevParams P, float* out,
-                                                     unsigned long long* counters) {
-  const uint32_t nbx = (P.nx + 15u) / 16u;
-  const uint32_t bx = blockIdx.x % nbx, by = blockIdx.x / nbx;
-  const uint32_t tiles_x = (P.nx + P.tile_w - 1u) / P.tile_w;
-  const uint32_t tile = ((by * 16u) / P.tile_h) * tiles_x + (bx * 16u) / P.tile_w;
-  if (tile % P.nranks != P.rank) return;
-  const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63u;
-  const uint32_t x = bx * 16u + (w & 1u) * 8u + (l & 7u);
-  const uint32_t row = by * 16u + (w >> 1) * 8u + (l >> 3);
-  if (x >= P.nx || row >= P.ny) return;
-  const uint32_t y = P.ny - 1u - row;  // lib.rs:328: row 0 is y = ny-1
-  Counts cnt = {0, 0, 0, 0};
-  uint32_t total_draws = 0;
-  V3 col = mk(0.f, 0.f, 0.f);
-  for (uint32_t s = 0; s < P.ns; s++) {
-    uint32_t bounces, draws;
-    V3 c = sample_color<FEAT, COUNT>(sc, cam, P, x, y, s, cnt, bounces, draws);
-    col = vadd(col, c);
-    if (COUNT) total_draws += draws;
-  }
-  col = sdiv(col, (float)P.ns);  // lib.rs:374
-  float* o = out + 3ull * ((size_t)row * P.nx + x);
-  o[0] = col.x, o[1] = col.y, o[2] = col.z;
-  if (COUNT) flush_counts(cnt, total_draws, counters);
-}
-
-template <uint32_t FEAT>
-__global__ void debug_hit_top_kernel(DevScene sc, uint32_t n, const float* rays, uint32_t seed_lo, uint32_t seed_hi,
-                                     float t_near, float* out, uint32_t* out_mat) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float* r = rays + 7ull * i;
-  SampleRng rng;
-  rng.init(((uint64_t)seed_hi << 32) | seed_lo, i, 0);
-  rng.set_event(1);
-  HitRec h;
-  Counts cnt = {0, 0, 0, 0};
-  bool hit = hit_top<FEAT, false>(sc, mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5]), r[6], t_near, rng, h, cnt);
-  float* o = out + 8ull * i;
-  o[0] = hit ? 1.f : 0.f;
-  o[1] = hit ? h.t : 0.f;
-  o[2] = hit ? h.p.x : 0.f, o[3] = hit ? h.p.y : 0.f, o[4] = hit ? h.p.z : 0.f;
-  o[5] = hit ? h.n.x : 0.f, o[6] = hit ? h.n.y : 0.f, o[7] = hit ? h.n.z : 0.f;
-  out_mat[i] = hit ? h.mat : 0xffffffffu;
-}
-
-template <uint32_t FEAT>
-__global__ void debug_samples_kernel(DevScene sc, DevCamera cam, DevParams P, uint32_t n, const uint32_t* xs,
-                                     const uint32_t* ys, const uint32_t* ss, float* out_rgb, uint32_t* out_info) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  Counts cnt = {0, 0, 0, 0};
-  uint32_t bounces = 0, draws = 0;
-  V3 c = sample_color<FEAT, true>(sc, cam, P, xs[i], ys[i], ss[i], cnt, bounces, draws);
-  out_rgb[3 * i] = c.x, out_rgb[3 * i + 1] = c.y, out_rgb[3 * i + 2] = c.z;
-  out_info[4 * i] = bounces, out_info[4 * i + 1] = draws, out_info[4 * i + 2] = cnt.aabb, out_info[4 * i + 3] = cnt.prim;
-}
-
-// print_ppm's to_u8 (lib.rs:348-352): sqrt, * 255.99, `as i32` (saturating, NaN -> 0), clamp 0..=255
-__global__ void tonemap_kernel(size_t n, const float* __restrict__ rgb, uint8_t* __restrict__ out) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float v = 255.99f * __builtin_sqrtf(rgb[i]);
-  int32_t q = f32_as_i32(v);
-  out[i] = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
-}
-
-__global__ void debug_math_kernel(int op, size_t n, const float* in, const float* in2, float* out) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float x = in[i];
-  float r;
-  switch (op) {
-    case 0: r = rt_logf(x); break;
-    case 1: r = rt_pow5f(x); break;
-    case 2: r = rt_sinf(x); break;
-    case 3: r = __builtin_sqrtf(x); break;
-    case 4: r = 1.f / x; break;
-    default: r = x / in2[i]; break;
-  }
-  out[i] = r;
-}
+#include "rtg_kernels.inc"
 
 // ===================================================================================================
 // Host side
@@ -202,359 +102,7 @@ struct rtg_scene {
   int pool_threads = 1024;                 // lean ray-pool kernel: ONE 16-wave workgroup per CU shares one LDS copy of the program
 };
 
-// The per-sample colour scratch may take up to half of the free HBM (288 GB per MI355X).
-static uint64_t scratch_cap() {
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 16ull << 30;
-  return (uint64_t)free_b / 2;
-}
-
-// Sample passes.  The pool kernels park every sample colour in a [sample][pixel work index] scratch (12 B each) that the
-// ordered fold consumes; a frame whose scratch would exceed the budget (option scratch_mb, default half of the free HBM)
-// or whose work items would overflow the 32-bit queue counter is rendered in several passes over consecutive sample
-// ranges, the fold kernel carrying the running per-pixel sum from pass to pass (rt_pool.h ChunkMode::s_begin) -- the
-// same left fold, bit for bit, with O(budget) instead of O(spp) memory.  Returns the samples per pass (>= 1).
-static uint32_t samples_per_pass(const rtg_scene* s, uint64_t pix_work, uint32_t ns) {
-  const uint64_t per_sample = pix_work * 3 * sizeof(float);
-  uint64_t budget = s->scratch_limit ? s->scratch_limit : std::max<uint64_t>(scratch_cap(), s->scratch_bytes);
-  if (s->whole_scratch) budget = ~0ull;
-  uint64_t k = std::max<uint64_t>(1, budget / std::max<uint64_t>(per_sample, 1));
-  k = std::min<uint64_t>(k, 0xfffffffeull / std::max<uint64_t>(pix_work, 1));  // work items of a pass: one 32-bit counter
-  k = std::max<uint64_t>(1, std::min<uint64_t>(k, ns));
-  const uint64_t n_pass = (ns + k - 1) / k;
-  return (uint32_t)((ns + n_pass - 1) / n_pass);  // balanced passes
-}
-
-static uint64_t owned_pixels(const DevParams& d);
-static hipError_t grow(void** buf, size_t* have, size_t need) {
-  if (need <= *have) return hipSuccess;
-  if (*buf) (void)hipFree(*buf);
-  *buf = nullptr, *have = 0;
-  hipError_t e = hipMalloc(buf, need);
-  if (e == hipSuccess) *have = need;
-  return e;
-}
-
-static hipError_t setup_lpt(rtg_scene* s, ChunkMode& cm, uint64_t capacity, hipStream_t stream);
-
-// Lean scenes, ray-pool kernel (rt_pool.h): one persistent 1024-thread workgroup per CU.
-template <bool COUNT>
-static hipError_t launch_pool(rtg_scene* s, const DevCamera& cam, const DevParams& d, float* d_out,
-                              hipStream_t stream) {
-  uint32_t tiles_x = (d.nx + d.tile_w - 1) / d.tile_w, tiles_y = (d.ny + d.tile_h - 1) / d.tile_h;
-  uint32_t tiles = tiles_x * tiles_y;
-  uint32_t owned = tiles > d.rank ? (tiles - d.rank + d.nranks - 1) / d.nranks : 0;
-  const uint64_t pix_work = (uint64_t)owned * d.tile_w * d.tile_h;
-  if (pix_work == 0) return hipSuccess;  // this rank owns no tile
-  if (pix_work > 0xfffffffeull) return hipErrorInvalidValue;
-  const int bt = s->pool_threads;
-  const uint32_t waves = (uint32_t)bt / 64;
-  // Sample-chunk mode (see rt_pool.h).  Default: one sample per work item.  Work items are then ~100x more numerous than
-  // path slots, so the end-of-frame tail (slots finishing their last item while the queue is empty) is negligible;
-  // measured on C2: 40.6 ms with one pixel (50 samples) per item, 23.5 ms with one sample per item.
-  uint64_t n_chunks = d.ns;
-  if (s->force_chunks > 0) n_chunks = (uint64_t)s->force_chunks;
-  if (n_chunks > d.ns) n_chunks = d.ns;
-  const bool use_scratch = n_chunks > 1;  // else (ns = 1, or option chunks = 1): a slot folds its pixel's samples itself
-  uint32_t per_pass = d.ns, chunk = d.ns;
-  if (use_scratch) {
-    per_pass = samples_per_pass(s, pix_work, d.ns);
-    chunk = (uint32_t)((d.ns + n_chunks - 1) / n_chunks);
-    if (per_pass < d.ns) chunk = 1u;  // several passes: one sample per work item
-    hipError_t ea = grow((void**)&s->d_scratch, &s->scratch_bytes, pix_work * per_pass * 3 * sizeof(float));
-    if (ea != hipSuccess) return ea;
-  }
-  s->last_pix_work = use_scratch && per_pass == d.ns ? (uint32_t)pix_work : 0u;
-  uint32_t* queue = (uint32_t*)(s->d_counters + 7);
-  const size_t lds_limit = 160 * 1024;
-  const bool wide = s->bvh4 && s->wide_bytes != 0;
-  const uint32_t image = wide ? s->wide_bytes : s->dev.lds_image_bytes;
-  DevScene dev = s->dev;
-  if (wide) dev.lds_off = (const uint32_t*)s->buffers[7], dev.lds_image_bytes = s->wide_bytes;  // the WIDE kernel's reading of these two
-  bool use_lds = image != 0 && pool_lds_bytes(image, s->n_mat, waves, true, false) <= lds_limit;
-  if (wide && !use_lds) return hipErrorNotSupported;  // (rtg_scene_set_option refuses bvh4 for images that do not fit)
-  // (hot slot fields in LDS keep best_pc as 16 bits = 14 bits of image offset / 8 + 2 bits of scatter tries: images < 128 KB)
-  bool ray_lds = s->ray_lds && pool_lds_bytes(image, s->n_mat, waves, use_lds, true) <= lds_limit && (!use_lds || image < (1u << 17));
-  size_t lds = pool_lds_bytes(image, s->n_mat, waves, use_lds, ray_lds);
-  void (*kernel)(DevScene, const LaunchConsts*, float*, uint32_t, uint32_t*, unsigned long long*, PoolTuning, uint32_t*);
-  if (wide) kernel = ray_lds ? render_lean_pool<true, COUNT, true, true> : render_lean_pool<true, COUNT, false, true>;
-  else if (ray_lds) kernel = use_lds ? render_lean_pool<true, COUNT, true> : render_lean_pool<false, COUNT, true>;
-  else kernel = use_lds ? render_lean_pool<true, COUNT, false> : render_lean_pool<false, COUNT, false>;
-  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  int per_cu = s->wg_per_cu;
-  if (per_cu <= 0) {
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, bt, lds);
-    if (e != hipSuccess) return e;
-  }
-  if (per_cu < 1) per_cu = 1;
-  for (uint32_t s0 = 0; s0 < d.ns; s0 += per_pass) {  // ONE pass unless the scratch budget is smaller than the frame's sample colours
-    DevParams dp = d;
-    dp.ns = std::min(d.ns, s0 + per_pass);  // the pass renders samples [s0, dp.ns)
-    ChunkMode cm{};
-    cm.scratch = nullptr, cm.chunk = d.ns, cm.n_chunks = 1, cm.pix_work = (uint32_t)pix_work, cm.s_begin = s0;
-    if (use_scratch) {
-      cm.chunk = chunk;
-      cm.n_chunks = (dp.ns - s0 + chunk - 1) / chunk;
-      cm.scratch = s->d_scratch - 3ull * s0 * pix_work;  // biased: sample s of work index w at scratch[3 * (s * pix_work + w)]
-    }
-    const uint64_t total_work = pix_work * cm.n_chunks;
-    if (total_work > 0xfffffffeull) return hipErrorInvalidValue;
-    e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream);  // re-initialise every pass
-    if (e != hipSuccess) return e;
-    // a wave keeps POOL paths in flight; do not launch more waves than there is work for
-    uint64_t want = (total_work + (uint64_t)waves * POOL - 1) / ((uint64_t)waves * POOL);
-    uint32_t grid = (uint32_t)std::min<uint64_t>(want ? want : 1, (uint64_t)s->num_cus * per_cu);
-    e = setup_lpt(s, cm, (uint64_t)grid * waves * POOL, stream);
-    if (e != hipSuccess) return e;
-    if (s->verbose)
-      fprintf(stderr, "[rtg] pool: samples [%u, %u) of %u: grid %u x %d threads, %d WG/CU, lds %zu B (program staged: %d, hot slot fields in LDS: %d), %u chunk(s) of %u samples, cost-ordered queue after %u chunk(s)\n",
-              s0, dp.ns, d.ns, grid, bt, per_cu, lds, (int)use_lds, (int)ray_lds, cm.n_chunks, cm.chunk, (cm.lpt_samples - (cm.lpt_samples ? s0 : 0u)) / (cm.chunk ? cm.chunk : 1u));
-    e = grow((void**)&s->d_slots, &s->slots_bytes, (size_t)grid * waves * POOL * POOL_FIELDS * sizeof(uint32_t));
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(write_launch_consts, dim3(1), dim3(1), 0, stream, s->d_consts, LaunchConsts{cam, dp, cm, make_pixmap(dp)});
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(bt), lds, stream, dev, (const LaunchConsts*)s->d_consts, d_out, (uint32_t)total_work, queue,
-                       s->d_counters, s->pool_tune, s->d_slots);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (cm.scratch) {
-      hipLaunchKernelGGL(fold_samples_kernel, dim3((uint32_t)((pix_work + 255) / 256)), dim3(256), 0, stream, dp, cm, make_pixmap(dp), d_out, d.ns);
-      e = hipGetLastError();
-      if (e != hipSuccess) return e;
-    }
-  }
-  return hipSuccess;
-}
-
-// The 4-wide image of a lean program that is ONE Bvh over spheres (rt_pool.h WIDE; option `bvh4`): every node record holds
-// the boxes of up to four GRANDCHILDREN of a node of the reference's tree (bvh.rs:22-81), in the reference's left-to-right
-// order, so that a traversal step tests four boxes at once and the leaves are still met in the reference's order.  Returns
-// false when the program has another shape (list-level objects, bare leaves, more than 8 levels).
-static bool build_wide_image(const Packet* lo, const Packet* hi, size_t n, std::vector<uint32_t>& out) {
-  struct T { uint32_t box; int left, right; uint32_t sphere; };  // left < 0: a leaf (box + sphere)
-  std::vector<T> nodes;
-  auto op_of = [&](size_t i) { return hi[i].w[3] & 0xffu; };
-  if (n < 4 || op_of(n - 1) != OP_END || op_of(0) != OP_BOX || hi[0].w[2] != n - 1) return false;
-  bool ok = true;
-  std::function<int(size_t, size_t&)> parse = [&](size_t i, size_t& end) -> int {
-    if (i >= n || op_of(i) != OP_BOX) { ok = false; end = i + 1; return -1; }
-    end = hi[i].w[2];
-    const int id = (int)nodes.size();
-    nodes.push_back(T{(uint32_t)i, -1, -1, 0});
-    if (op_of(i + 1) == OP_SPHERE) {
-      if (end != i + 2) ok = false;
-      nodes[id].sphere = (uint32_t)(i + 1);
-      return id;
-    }
-    size_t e1 = 0, e2 = 0;
-    const int l = parse(i + 1, e1);
-    if (!ok || e1 >= end) { ok = false; return id; }
-    const int r = parse(e1, e2);
-    if (e2 != end) ok = false;
-    nodes[id].left = l, nodes[id].right = r;
-    return id;
-  };
-  size_t end0 = 0;
-  const int root = parse(0, end0);
-  if (!ok || root < 0 || nodes[root].left < 0) return false;
-  out.clear();
-  auto alloc = [&](uint32_t bytes) { const uint32_t at = (uint32_t)out.size() * 4u; out.resize(out.size() + bytes / 4u, 0u); return at; };
-  std::function<uint32_t(int, uint32_t, uint32_t)> emit = [&](int t, uint32_t parent, uint32_t level) -> uint32_t {
-    if (level > 7u) { ok = false; return 0; }
-    const uint32_t at = alloc(WIDE_NODE_BYTES);
-    int entry[4];
-    uint32_t n_ch = 0;
-    for (int x : {nodes[t].left, nodes[t].right}) {
-      if (nodes[x].left < 0) entry[n_ch++] = x;
-      else entry[n_ch++] = nodes[x].left, entry[n_ch++] = nodes[x].right;
-    }
-    uint32_t child[4] = {0, 0, 0, 0}, leafmask = 0;
-    for (uint32_t k = 0; k < n_ch; k++) {
-      const T e = nodes[entry[k]];
-      const Packet bl = lo[e.box], bh = hi[e.box];  // (min.x, max.x, min.y, max.y) (min.z, max.z, ..)
-      uint32_t* b = out.data() + at / 4u + 4u + 12u * k;  // (min, max) pairs, then (max, min) pairs: rt_pool.h
-      b[0] = bl.w[0], b[1] = bl.w[1], b[2] = bl.w[2], b[3] = bl.w[3], b[4] = bh.w[0], b[5] = bh.w[1];
-      b[6] = bl.w[1], b[7] = bl.w[0], b[8] = bl.w[3], b[9] = bl.w[2], b[10] = bh.w[1], b[11] = bh.w[0];
-      if (e.left < 0) {
-        const uint32_t sp = alloc(WIDE_SPHERE_BYTES);
-        uint32_t* r = out.data() + sp / 4u;
-        r[0] = hi[e.sphere].w[2], r[1] = hi[e.sphere].w[3];
-        r[2] = lo[e.sphere].w[0], r[3] = lo[e.sphere].w[1], r[4] = lo[e.sphere].w[2], r[5] = lo[e.sphere].w[3];
-        r[6] = at, r[7] = 0u;
-        child[k] = sp, leafmask |= 1u << k;
-      } else {
-        child[k] = emit(entry[k], at, level + 1u);
-      }
-    }
-    uint32_t* h = out.data() + at / 4u;
-    h[0] = parent, h[1] = LDS_BOX_BIT | OP_BOX | (level << 8) | (n_ch << 12) | (leafmask << 16);
-    h[2] = (child[0] >> 3) | ((child[1] >> 3) << 16), h[3] = (child[2] >> 3) | ((child[3] >> 3) << 16);
-    return at;
-  };
-  emit(root, WIDE_NO_PARENT, 0u);
-  return ok && out.size() * 4u < 512u * 1024u;
-}
-
-// Cost-ordered work queue (rt_pool.h, ChunkMode): enabled when the frame has enough chunks for a measuring
-// phase and enough blocks to order; the buffers are re-zeroed on the launch stream every call.
-static hipError_t setup_lpt(rtg_scene* s, ChunkMode& cm, uint64_t capacity, hipStream_t stream) {
-  cm.lpt = nullptr, cm.lpt_samples = 0, cm.lpt_deep = 0;
-  const uint32_t n_blocks = cm.pix_work / LPT_BLOCK;
-  if (!s->lpt || !cm.scratch || cm.n_chunks < 6 || n_blocks < 64 || n_blocks > 65536 || cm.pix_work % LPT_BLOCK) return hipSuccess;
-  // Phase 1 must outlast the first fill of the pools (`capacity` paths in flight) by enough for the
-  // counts to mean something when the blocks are filed; it may take up to a third of the frame.
-  uint32_t phase1 = std::max<uint32_t>(std::min(8u, std::max(2u, cm.n_chunks / 8u)), (uint32_t)((2 * capacity + cm.pix_work - 1) / cm.pix_work));
-  if (s->lpt_phase1 > 0) phase1 = (uint32_t)s->lpt_phase1;
-  if (phase1 < 1 || phase1 > cm.n_chunks / 3) return hipSuccess;
-  // layout: [descriptor, 64 B] [cost n] [ctl LPT_CTL] [list LPT_CLASSES x n]
-  const size_t words = 16 + (size_t)n_blocks * (1 + LPT_CLASSES) + LPT_CTL;
-  hipError_t e = grow((void**)&s->d_lpt, &s->lpt_bytes, words * sizeof(uint32_t));
-  if (e != hipSuccess) return e;
-  LptQueue q;
-  memset(&q, 0, sizeof(q));
-  static_assert(sizeof(LptQueue) <= 64, "descriptor slot");
-  q.cost = s->d_lpt + 16, q.ctl = q.cost + n_blocks, q.list = q.ctl + LPT_CTL;
-  q.n_blocks = n_blocks, q.phase1 = phase1;
-  q.phase2_base = phase1 * cm.pix_work;
-  q.span = LPT_BLOCK * (cm.n_chunks - phase1);
-  q.mode = (uint32_t)s->lpt, q.shift = (uint32_t)s->lpt_shift;
-  // descriptor and zeroed counters travel on the launch stream: ordered with the render kernels before and after
-  hipLaunchKernelGGL(write_lpt_descriptor, dim3(1), dim3(1), 0, stream, reinterpret_cast<LptQueue*>(s->d_lpt), q);
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  s->lpt_desc = q;
-  e = hipMemsetAsync(q.cost, 0, ((size_t)n_blocks + LPT_CTL) * sizeof(uint32_t), stream);
-  if (e != hipSuccess) return e;
-  cm.lpt = reinterpret_cast<const LptQueue*>(s->d_lpt);
-  cm.lpt_samples = cm.s_begin + phase1 * cm.chunk;  // samples [s_begin, lpt_samples) of every pixel: phase 1 of this pass
-  cm.lpt_deep = (uint32_t)s->lpt_deep;
-  return hipSuccess;
-}
-
-// Full-feature scenes, ray-pool kernel (rt_pool_full.h) or, for list worlds without a Bvh, the lock-step kernel
-// (rt_sync_full.h): always one sample per work item + ordered fold, in as many sample passes as the scratch budget asks for.
-template <bool COUNT>
-static hipError_t launch_full_pool(rtg_scene* s, const DevCamera& cam, const DevParams& d, float* d_out,
-                                   hipStream_t stream) {
-  uint32_t tiles_x = (d.nx + d.tile_w - 1) / d.tile_w, tiles_y = (d.ny + d.tile_h - 1) / d.tile_h;
-  uint32_t tiles = tiles_x * tiles_y;
-  uint32_t owned = tiles > d.rank ? (tiles - d.rank + d.nranks - 1) / d.nranks : 0;
-  const uint64_t pix_work = (uint64_t)owned * d.tile_w * d.tile_h;
-  if (pix_work == 0) return hipSuccess;
-  if (pix_work > 0xfffffffeull) return hipErrorInvalidValue;
-  const uint32_t per_pass = samples_per_pass(s, pix_work, d.ns);
-  const bool tex = (s->features & FEAT_TEXTURE) != 0;
-  // ONE 16-wave workgroup per CU shares one LDS copy of the program (128 VGPRs per lane).
-  const int bt_max = tex ? RT_FULL_TEX_THREADS : 1024;
-  const int bt = s->full_threads > 0 && s->full_threads <= bt_max ? s->full_threads : bt_max;
-  const uint32_t waves = (uint32_t)bt / 64;
-  hipError_t e = grow((void**)&s->d_scratch, &s->scratch_bytes, pix_work * per_pass * 3 * sizeof(float));
-  if (e != hipSuccess) return e;
-  s->last_pix_work = per_pass == d.ns ? (uint32_t)pix_work : 0u;
-  uint32_t* queue = (uint32_t*)(s->d_counters + 7);
-  // Program placement: the whole program in LDS when it fits, else a leading window
-  // (depth-first order: the window holds whole leading subtrees) and global memory for the rest.
-  const size_t list_bytes = full_pool_lds_bytes(0, waves);
-  const size_t budget = 160 * 1024;  // all of a CU's LDS: one workgroup per CU
-  uint32_t window = s->n_prog;
-  int prog = 1;
-  if ((size_t)window * 32 + list_bytes > budget) window = (uint32_t)((budget - list_bytes) / 32), prog = 2;
-  if (s->window >= 0) {
-    window = std::min<uint32_t>(s->n_prog, (uint32_t)s->window);
-    prog = window == 0 ? 0 : (window == s->n_prog ? 1 : 2);
-  }
-  const size_t lds = full_pool_lds_bytes(window, waves);
-  void (*kernel)(DevScene, const LaunchConsts*, float*, uint32_t, uint32_t*, unsigned long long*, PoolTuning, uint32_t*, float*,
-                 uint32_t);
-  const bool genb = (s->features & FEAT_BOUNDARY) != 0;  // a medium bounded by an object graph: the nested-walk variant
-  if (genb) {
-    if (prog == 0) kernel = tex ? render_full_pool<0, true, COUNT, true> : render_full_pool<0, false, COUNT, true>;
-    else if (prog == 1) kernel = tex ? render_full_pool<1, true, COUNT, true> : render_full_pool<1, false, COUNT, true>;
-    else kernel = tex ? render_full_pool<2, true, COUNT, true> : render_full_pool<2, false, COUNT, true>;
-  } else if (prog == 0) kernel = tex ? render_full_pool<0, true, COUNT> : render_full_pool<0, false, COUNT>;
-  else if (prog == 1) kernel = tex ? render_full_pool<1, true, COUNT> : render_full_pool<1, false, COUNT>;
-  else kernel = tex ? render_full_pool<2, true, COUNT> : render_full_pool<2, false, COUNT>;
-  e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  int per_cu = s->wg_per_cu;
-  if (per_cu <= 0) {
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, bt, lds);
-    if (e != hipSuccess) return e;
-  }
-  if (per_cu < 1) per_cu = 1;
-  const bool lock_step = (s->sync_full > 0 || (s->sync_full < 0 && s->n_box == 0)) && prog == 1;  // list world without a Bvh: one path per lane (rt_sync_full.h)
-  void (*k2)(DevScene, const LaunchConsts*, float*, uint32_t, uint32_t*, unsigned long long*, PoolTuning, float*, uint32_t) = nullptr;
-  const size_t lds2 = (size_t)window * 32;
-  if (lock_step) {
-    if (genb) k2 = tex ? render_full_sync<1, true, COUNT, true> : render_full_sync<1, false, COUNT, true>;
-    else k2 = tex ? render_full_sync<1, true, COUNT, false> : render_full_sync<1, false, COUNT, false>;
-    e = hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    if (e != hipSuccess) return e;
-  }
-  for (uint32_t s0 = 0; s0 < d.ns; s0 += per_pass) {  // ONE pass unless the scratch budget is smaller than the frame's sample colours
-    DevParams dp = d;
-    dp.ns = std::min(d.ns, s0 + per_pass);
-    ChunkMode cm{};
-    cm.scratch = s->d_scratch - 3ull * s0 * pix_work, cm.chunk = 1u, cm.n_chunks = dp.ns - s0, cm.pix_work = (uint32_t)pix_work, cm.s_begin = s0;
-    const uint64_t total_work = pix_work * cm.n_chunks;
-    if (total_work > 0xfffffffeull) return hipErrorInvalidValue;
-    e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream);
-    if (e != hipSuccess) return e;
-    uint64_t want = (total_work + (uint64_t)waves * FPOOL - 1) / ((uint64_t)waves * FPOOL);
-    uint32_t grid = (uint32_t)std::min<uint64_t>(want ? want : 1, (uint64_t)s->num_cus * per_cu);
-    e = setup_lpt(s, cm, (uint64_t)grid * waves * FPOOL, stream);
-    if (e != hipSuccess) return e;
-    e = grow((void**)&s->d_slots, &s->slots_bytes, (size_t)grid * waves * FPOOL * FPOOL_FIELDS * sizeof(uint32_t));
-    if (e != hipSuccess) return e;
-    e = grow((void**)&s->d_stack, &s->stack_bytes, (size_t)grid * waves * (genb ? 2 : 1) * MAX_XFORM_DEPTH * 6 * 64 * sizeof(float));
-    if (e != hipSuccess) return e;
-    if (s->verbose)
-      fprintf(stderr, "[rtg] full pool: samples [%u, %u) of %u: grid %u x %d threads, %d WG/CU, lds %zu B (program window: %u of %u records), cost-ordered queue after %u chunk(s)\n",
-              s0, dp.ns, d.ns, grid, bt, per_cu, lds, window, s->n_prog, cm.lpt_samples - (cm.lpt_samples ? s0 : 0u));
-    hipLaunchKernelGGL(write_launch_consts, dim3(1), dim3(1), 0, stream, s->d_consts, LaunchConsts{cam, dp, cm, make_pixmap(dp)});
-    if (lock_step)
-      hipLaunchKernelGGL(k2, dim3(grid), dim3(bt), lds2, stream, s->dev, (const LaunchConsts*)s->d_consts, d_out, (uint32_t)total_work, queue,
-                         s->d_counters, s->sync_tune, s->d_stack, window);
-    else
-      hipLaunchKernelGGL(kernel, dim3(grid), dim3(bt), lds, stream, s->dev, (const LaunchConsts*)s->d_consts, d_out, (uint32_t)total_work, queue,
-                         s->d_counters, s->full_tune, s->d_slots, s->d_stack, window);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fold_samples_kernel, dim3((uint32_t)((pix_work + 255) / 256)), dim3(256), 0, stream, dp, cm, make_pixmap(dp), d_out, d.ns);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-  }
-  return hipSuccess;
-}
-
-template <bool COUNT>
-static hipError_t launch_render(rtg_scene* s, const DevCamera& cam, const DevParams& d, float* d_out,
-                                hipStream_t stream) {
-  // geometry / texture features pick the kernel; the albedo-range bits only say whether the pool kernels' "accum
-  // is +0" argument holds (rt_pool.h PoolField)
-  const uint32_t geom = s->features & (FEAT_ALL | FEAT_BOUNDARY);
-  const bool accum_zero = !(s->features & FEAT_WIDE_ALBEDO) && (!(s->features & FEAT_BRIGHT_ALBEDO) || d.max_bounces <= 63u);
-  // FEAT_DEEP: graph shapes only the general walk of the baseline kernel handles (flat_scene.h)
-  const bool pool_ok = accum_zero && s->kernel_version >= 3 && d.nx <= 0xffffu && d.ny <= 0xffffu && !(s->features & FEAT_DEEP);
-  s->last_kernel = 1;
-  if (geom != 0 && pool_ok) {
-    s->last_kernel = 4;
-    return launch_full_pool<COUNT>(s, cam, d, d_out, stream);
-  }
-  if (geom == 0 && pool_ok) {
-    s->last_kernel = 3;
-    return launch_pool<COUNT>(s, cam, d, d_out, stream);
-  }
-  uint32_t nbx = (d.nx + 15) / 16, nby = (d.ny + 15) / 16;
-  dim3 grid(nbx * nby), block(256);
-  if (s->features & FEAT_DEEP)
-    hipLaunchKernelGGL((render_kernel<FEAT_ALL | FEAT_DEEP, COUNT>), grid, block, 0, stream, s->dev, cam, d, d_out, s->d_counters);
-  else if (geom == 0)
-    hipLaunchKernelGGL((render_kernel<0u, COUNT>), grid, block, 0, stream, s->dev, cam, d, d_out, s->d_counters);
-  else
-    hipLaunchKernelGGL((render_kernel<FEAT_ALL, COUNT>), grid, block, 0, stream, s->dev, cam, d, d_out, s->d_counters);
-  return hipGetLastError();
-}
+#include "rtg_launch.inc"
 
 template <typename T>
 struct DevBuf {
@@ -1083,420 +631,8 @@ int rtg_par_cast(rtg_scene* s, const rtg_camera* camera, const rtg_params* param
   return rc;
 }
 
-// ---- single-process multi-GPU par_cast ---------------------------------------------------
-// RCCL is dlopen()ed on first use (more than one distinct device, or the `force_rccl` option), so librtiow_gpu.so carries
-// no link-time dependency on it and one-GPU hosts never load it.
-namespace {
-struct Rccl {
-  void* lib = nullptr;
-  std::string path;  // rtg_multi_reset: the library to load instead of the default search ("" = default)
-  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
-  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  ncclResult_t (*GroupStart)() = nullptr;
-  ncclResult_t (*GroupEnd)() = nullptr;
-  ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
-  const char* (*GetErrorString)(ncclResult_t) = nullptr;
-  std::map<std::vector<int>, std::vector<ncclComm_t>> comms;  // one clique per device list, created once, destroyed by rtg_multi_reset
-  uint64_t n_reduces = 0;                                      // ncclReduce calls issued (rtg_multi_reset reports and clears it)
-  std::mutex mu;
-};
-Rccl g_rccl;
+#include "rtg_multi.inc"
 
-// (g_rccl.mu held)
-bool rccl_load(std::string* why) {
-  if (g_rccl.lib) return true;
-  void* h = nullptr;
-  std::string tried;
-  auto attempt = [&](const char* n, int flags) {
-    if (h) return;
-    (void)dlerror();
-    h = dlopen(n, flags);
-    if (!h && !(flags & RTLD_NOLOAD)) {
-      const char* e = dlerror();  // ONE call: dlerror() clears the message it returns
-      tried += std::string(tried.empty() ? "" : "; ") + (e ? e : n);
-    }
-  };
-  if (!g_rccl.path.empty()) {
-    attempt(g_rccl.path.c_str(), RTLD_NOW | RTLD_LOCAL);
-  } else {
-    // an already-loaded librccl (e.g. the one a host framework ships) first, then the ROCm installation's
-    for (const char* n : {"librccl.so", "librccl.so.1"}) attempt(n, RTLD_NOW | RTLD_NOLOAD);
-    for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) attempt(n, RTLD_NOW | RTLD_LOCAL);
-  }
-  if (!h) {
-    *why = "librccl not loadable: " + (tried.empty() ? std::string("?") : tried);
-    return false;
-  }
-  auto sym = [&](const char* n) { return dlsym(h, n); };
-  g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))sym("ncclCommInitAll");
-  g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
-  g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
-  g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
-  g_rccl.Reduce = (decltype(g_rccl.Reduce))sym("ncclReduce");
-  g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
-  if (!g_rccl.CommInitAll || !g_rccl.CommDestroy || !g_rccl.GroupStart || !g_rccl.GroupEnd || !g_rccl.Reduce || !g_rccl.GetErrorString) {
-    *why = "librccl lacks ncclCommInitAll / ncclCommDestroy / ncclGroupStart / ncclGroupEnd / ncclReduce / ncclGetErrorString";
-    dlclose(h);
-    return false;
-  }
-  g_rccl.lib = h;
-  return true;
-}
-
-// (g_rccl.mu held) destroy the cached cliques
-void rccl_drop_comms() {
-  if (g_rccl.CommDestroy)
-    for (auto& kv : g_rccl.comms)
-      for (ncclComm_t c : kv.second)
-        if (c) (void)g_rccl.CommDestroy(c);
-  g_rccl.comms.clear();
-}
-
-// ONE collective over the distinct devices: reduce(sum) of the float3 framebuffers heads[k]->d_frame (device devs[k],
-// stream heads[k]->own_stream) to heads[0]'s.  On any failure the group is still closed and the communicators of this
-// device list are dropped (their state is unknown); the caller synchronizes the streams.
-int rccl_reduce_frames(const std::vector<int>& devs, const std::vector<rtg_scene*>& heads, size_t n_floats) {
-  std::lock_guard<std::mutex> lock(g_rccl.mu);
-  std::string why;
-  if (!rccl_load(&why)) return fail(RTG_ERR_DEVICE, why);
-  auto it = g_rccl.comms.find(devs);
-  if (it == g_rccl.comms.end()) {
-    std::vector<ncclComm_t> c(devs.size(), nullptr);
-    ncclResult_t r = g_rccl.CommInitAll(c.data(), (int)devs.size(), devs.data());
-    if (r != ncclSuccess) return fail(RTG_ERR_DEVICE, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r));
-    it = g_rccl.comms.emplace(devs, std::move(c)).first;
-  }
-  std::string err;
-  ncclResult_t r = g_rccl.GroupStart();
-  if (r != ncclSuccess) {
-    err = std::string("ncclGroupStart: ") + g_rccl.GetErrorString(r);
-  } else {
-    for (size_t k = 0; k < devs.size() && err.empty(); k++) {
-      hipError_t he = hipSetDevice(devs[k]);
-      if (he != hipSuccess) {
-        err = std::string("hipSetDevice: ") + hipGetErrorString(he);
-        break;
-      }
-      r = g_rccl.Reduce(heads[k]->d_frame, heads[k]->d_frame, n_floats, ncclFloat, ncclSum, 0, it->second[k], heads[k]->own_stream);
-      if (r != ncclSuccess) err = std::string("ncclReduce: ") + g_rccl.GetErrorString(r);
-      else g_rccl.n_reduces++;
-    }
-    const ncclResult_t r2 = g_rccl.GroupEnd();  // always: a group left open would swallow every later RCCL call of the process
-    if (r2 != ncclSuccess && err.empty()) err = std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(r2);
-  }
-  if (!err.empty()) {
-    for (ncclComm_t c : it->second)
-      if (c) (void)g_rccl.CommDestroy(c);
-    g_rccl.comms.erase(it);
-    return fail(RTG_ERR_DEVICE, err);
-  }
-  return RTG_OK;
-}
-
-__global__ void add_frames_kernel(size_t n, float* __restrict__ dst, const float* __restrict__ src) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = dst[i] + src[i];  // every pixel has ONE non-zero contributor: x + 0 is exact
-}
-
-int par_cast_multi_body(rtg_scene* const* scenes, int n_scenes, const rtg_camera* camera, const rtg_params* params, float* out_rgb,
-                        rtg_stats* stats) {
-  const size_t n_floats = (size_t)params->nx * params->ny * 3;
-  const size_t bytes = n_floats * sizeof(float);
-  const bool count = stats && (params->flags & RTG_FLAG_COUNTERS);
-  // (1) every scene renders ITS tiles (tile % n_scenes == i) into its own zero-filled full frame, on its own stream
-  for (int i = 0; i < n_scenes; i++) {
-    rtg_scene* s = scenes[i];
-    HIP_TRY(hipSetDevice(s->device));
-    if (!s->own_stream) HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
-    hipError_t e = grow((void**)&s->d_frame, &s->frame_bytes, bytes ? bytes : 16);
-    if (e != hipSuccess) return hip_fail(e, "hipMalloc(framebuffer)");
-    HIP_TRY(hipMemsetAsync(s->d_frame, 0, bytes, s->own_stream));
-    rtg_params p = *params;
-    p.rank = (uint32_t)i, p.nranks = (uint32_t)n_scenes;
-    DevParams d;
-    int rc = check_params(s, camera, &p, &d);
-    if (rc) return rc;
-    if (count) {
-      HIP_TRY(hipMemsetAsync(s->d_counters, 0, 7 * sizeof(unsigned long long), s->own_stream));
-      HIP_TRY(hipMemsetAsync(s->d_counters + 8, 0, 24 * sizeof(unsigned long long), s->own_stream));
-    }
-    HIP_TRY(hipEventRecord(s->ev0, s->own_stream));
-    const DevCamera cam = to_dev(camera);
-    HIP_TRY(count ? launch_render<true>(s, cam, d, s->d_frame, s->own_stream) : launch_render<false>(s, cam, d, s->d_frame, s->own_stream));
-    HIP_TRY(hipEventRecord(s->ev1, s->own_stream));
-  }
-  // (2) scenes that share a device with an earlier one are summed there; one frame per DISTINCT device remains
-  std::vector<int> devs;          // distinct devices in order of first appearance
-  std::vector<rtg_scene*> heads;  // the scene holding each device's partial frame
-  bool force_rccl = false;
-  for (int i = 0; i < n_scenes; i++) {
-    rtg_scene* s = scenes[i];
-    force_rccl = force_rccl || s->force_rccl != 0;
-    size_t k = 0;
-    while (k < devs.size() && devs[k] != s->device) k++;
-    if (k == devs.size()) {
-      devs.push_back(s->device), heads.push_back(s);
-      continue;
-    }
-    HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipStreamSynchronize(s->own_stream));
-    hipLaunchKernelGGL(add_frames_kernel, dim3((uint32_t)((n_floats + 255) / 256)), dim3(256), 0, heads[k]->own_stream, n_floats,
-                       heads[k]->d_frame, s->d_frame);
-    HIP_TRY(hipGetLastError());
-  }
-  // (3) ONE collective over the distinct devices: reduce(sum) of the float3 framebuffer to the first device (xGMI).
-  // `force_rccl`: also with ONE distinct device (a clique of one) -- the same dlopen / ncclCommInitAll / grouped in-place
-  // ncclReduce code as on a node, which one-GPU test boxes could otherwise never execute.
-  if (devs.size() > 1 || force_rccl) {
-    int rc = rccl_reduce_frames(devs, heads, n_floats);
-    if (rc) return rc;
-  }
-  // (4) wait, copy the assembled frame out, gather stats (kernel time = the slowest shard)
-  for (rtg_scene* h : heads) {
-    HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamSynchronize(h->own_stream));
-  }
-  HIP_TRY(hipSetDevice(heads[0]->device));
-  HIP_TRY(hipMemcpy(out_rgb, heads[0]->d_frame, bytes, hipMemcpyDeviceToHost));
-  if (stats) {
-    rtg_stats total{};
-    total.struct_size = sizeof(rtg_stats);
-    for (int i = 0; i < n_scenes; i++) {
-      rtg_scene* s = scenes[i];
-      HIP_TRY(hipSetDevice(s->device));
-      float ms = 0.f;
-      HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
-      total.kernel_ms = std::max(total.kernel_ms, ms);
-      rtg_params p = *params;
-      p.rank = (uint32_t)i, p.nranks = (uint32_t)n_scenes;
-      DevParams d;
-      (void)check_params(s, camera, &p, &d);
-      total.samples += owned_pixels(d) * d.ns;
-      if (count) {
-        unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        HIP_TRY(hipMemcpy(h, s->d_counters, sizeof(h), hipMemcpyDeviceToHost));
-        total.aabb_tests += h[0], total.prim_tests += h[1], total.shaded_hits += h[2], total.rays += h[3], total.draws += h[4];
-      }
-    }
-    *stats = total;
-  }
-  return RTG_OK;
-}
-}  // namespace
-
-int rtg_par_cast_multi(rtg_scene* const* scenes, int n_scenes, const rtg_camera* camera, const rtg_params* params,
-                       float* out_rgb, rtg_stats* stats) {
-  if (!scenes || n_scenes <= 0 || !camera || !params || !out_rgb) return fail(RTG_ERR_INVALID, "null argument");
-  if (params->struct_size != sizeof(rtg_params)) return fail(RTG_ERR_INVALID, "rtg_params.struct_size mismatch");
-  if (params->nranks > 1u) return fail(RTG_ERR_INVALID, "rtg_par_cast_multi shards by itself: params.rank / nranks must be 0 / 0|1");
-  if (stats && stats->struct_size != sizeof(rtg_stats)) return fail(RTG_ERR_INVALID, "rtg_stats.struct_size mismatch");
-  for (int i = 0; i < n_scenes; i++) {
-    if (!scenes[i]) return fail(RTG_ERR_INVALID, "null scene handle");
-    // one handle = one frame, one work queue, one stream: the same handle twice would wipe its own tiles
-    for (int k = 0; k < i; k++)
-      if (scenes[k] == scenes[i]) return fail(RTG_ERR_INVALID, "rtg_par_cast_multi: the same scene handle appears twice (one handle per shard)");
-  }
-  const int rc = par_cast_multi_body(scenes, n_scenes, camera, params, out_rgb, stats);
-  if (rc != RTG_OK) {
-    // whatever was queued before the failure must not outlive the call (the caller may free out_rgb, destroy the handles
-    // or call again): drain every stream that may hold work, keeping the first error message
-    const std::string first = g_err;
-    for (int i = 0; i < n_scenes; i++) {
-      if (!scenes[i]->own_stream) continue;
-      if (hipSetDevice(scenes[i]->device) == hipSuccess) (void)hipStreamSynchronize(scenes[i]->own_stream);
-    }
-    g_err = first;
-  }
-  return rc;
-}
-
-int rtg_multi_reset(const char* rccl_library_or_null, uint64_t* n_reduces_or_null) {
-  std::lock_guard<std::mutex> lock(g_rccl.mu);
-  if (n_reduces_or_null) *n_reduces_or_null = g_rccl.n_reduces;
-  g_rccl.n_reduces = 0;
-  rccl_drop_comms();
-  if (g_rccl.lib) dlclose(g_rccl.lib);
-  g_rccl.lib = nullptr;
-  g_rccl.CommInitAll = nullptr, g_rccl.CommDestroy = nullptr, g_rccl.GroupStart = nullptr, g_rccl.GroupEnd = nullptr;
-  g_rccl.Reduce = nullptr, g_rccl.GetErrorString = nullptr;
-  g_rccl.path = rccl_library_or_null ? rccl_library_or_null : "";
-  return RTG_OK;
-}
-
-// ---- probes --------------------------------------------------------------------------------------
-int rtg_debug_hit_top(rtg_scene* s, size_t n, const float* rays, uint64_t seed, float t_near, float* out,
-                      uint32_t* out_material) {
-  if (!s || !rays || !out || !out_material) return fail(RTG_ERR_INVALID, "null argument");
-  HIP_TRY(hipSetDevice(s->device));
-  DevBuf<float> d_rays, d_out;
-  DevBuf<uint32_t> d_mat;
-  HIP_TRY(d_rays.alloc(7 * n));
-  HIP_TRY(d_out.alloc(8 * n));
-  HIP_TRY(d_mat.alloc(n));
-  HIP_TRY(hipMemcpy(d_rays.p, rays, 7 * n * sizeof(float), hipMemcpyHostToDevice));
-  dim3 grid((uint32_t)((n + 63) / 64)), block(64);
-  if (n) {
-    if (s->features & FEAT_DEEP)
-      hipLaunchKernelGGL((debug_hit_top_kernel<FEAT_ALL | FEAT_DEEP>), grid, block, 0, 0, s->dev, (uint32_t)n, d_rays.p, (uint32_t)seed,
-                         (uint32_t)(seed >> 32), t_near, d_out.p, d_mat.p);
-    else if (s->features == 0)
-      hipLaunchKernelGGL((debug_hit_top_kernel<0u>), grid, block, 0, 0, s->dev, (uint32_t)n, d_rays.p, (uint32_t)seed,
-                         (uint32_t)(seed >> 32), t_near, d_out.p, d_mat.p);
-    else
-      hipLaunchKernelGGL((debug_hit_top_kernel<FEAT_ALL>), grid, block, 0, 0, s->dev, (uint32_t)n, d_rays.p,
-                         (uint32_t)seed, (uint32_t)(seed >> 32), t_near, d_out.p, d_mat.p);
-  }
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out, d_out.p, 8 * n * sizeof(float), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(out_material, d_mat.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  return RTG_OK;
-}
-
-int rtg_debug_samples(rtg_scene* s, const rtg_camera* camera, const rtg_params* params, size_t n, const uint32_t* xs,
-                      const uint32_t* ys, const uint32_t* samples, float* out_rgb, uint32_t* out_info) {
-  DevParams d;
-  int rc = check_params(s, camera, params, &d);
-  if (rc) return rc;
-  if (!xs || !ys || !samples || !out_rgb || !out_info) return fail(RTG_ERR_INVALID, "null argument");
-  HIP_TRY(hipSetDevice(s->device));
-  if (params->flags & RTG_FLAG_TRACE_KERNEL) {
-    // Trace the PRODUCTION kernel: render the whole frame with the instrumented variant of whatever kernel par_cast
-    // uses for this scene, with its per-sample trace table switched on, then pick the requested keys out of the table
-    // (colour: the per-sample scratch the ordered fold reads).
-    const uint32_t tiles_x = (d.nx + d.tile_w - 1) / d.tile_w, tiles_y = (d.ny + d.tile_h - 1) / d.tile_h;
-    const uint32_t tiles = tiles_x * tiles_y;
-    const uint64_t owned = tiles > d.rank ? (tiles - d.rank + d.nranks - 1) / d.nranks : 0;
-    const uint64_t pix_work = owned * d.tile_w * d.tile_h;
-    // per-slot accumulators, indexed by (workgroup * waves + wave): a CU holds at most 32 waves of these kernels, and the
-    // `wg_per_cu` option may ask for more (queued) workgroups of up to 16 waves each
-    const size_t trace_waves = (size_t)s->num_cus * std::max(32, s->wg_per_cu > 0 ? s->wg_per_cu * 16 : 0);
-    const size_t table = (size_t)4 * d.ns * pix_work, slots = trace_waves * std::max(FPOOL, POOL) * 3;
-    DevBuf<uint32_t> d_trace;
-    HIP_TRY(d_trace.alloc(table + slots));
-    HIP_TRY(hipMemset(d_trace.p, 0, (table + slots) * sizeof(uint32_t)));
-    HIP_TRY(grow((void**)&s->d_frame, &s->frame_bytes, (size_t)d.nx * d.ny * 3 * sizeof(float)));
-    HIP_TRY(hipMemset(s->d_counters, 0, 32 * sizeof(unsigned long long)));
-    const unsigned long long ptrs[2] = {(unsigned long long)(uintptr_t)d_trace.p, (unsigned long long)(uintptr_t)(d_trace.p + table)};
-    HIP_TRY(hipMemcpy(s->d_counters + 30, ptrs, sizeof(ptrs), hipMemcpyHostToDevice));
-    const DevCamera cam = to_dev(camera);
-    s->whole_scratch = true;  // the trace reads every sample colour back: one sample pass
-    hipError_t e = launch_render<true>(s, cam, d, s->d_frame, nullptr);
-    s->whole_scratch = false;
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    (void)hipMemset(s->d_counters + 30, 0, 2 * sizeof(unsigned long long));
-    if (e != hipSuccess) return hip_fail(e, "trace launch");
-    if (s->last_kernel < 3 || s->last_pix_work == 0)
-      return fail(RTG_ERR_UNSUPPORTED, "this scene / frame runs on the baseline kernel (or without the per-sample scratch): nothing to trace");
-    std::vector<uint32_t> h_trace(table);
-    std::vector<float> h_col((size_t)3 * d.ns * pix_work);
-    HIP_TRY(hipMemcpy(h_trace.data(), d_trace.p, table * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(h_col.data(), s->d_scratch, h_col.size() * sizeof(float), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < n; i++) {
-      const uint32_t x = xs[i], row = d.ny - 1u - ys[i], sm = samples[i];
-      const uint32_t tx = x / d.tile_w, ty = row / d.tile_h, tile = ty * tiles_x + tx;
-      if (x >= d.nx || ys[i] >= d.ny || sm >= d.ns || tile % d.nranks != d.rank) return fail(RTG_ERR_INVALID, "trace key outside this rank's frame");
-      const uint32_t k = tile / d.nranks, lx = x - tx * d.tile_w, ly = row - ty * d.tile_h;  // = pixel_to_work (rt_pool.h)
-      const uint32_t b = (ly >> 3) * (d.tile_w >> 3) + (lx >> 3);
-      const size_t w = (size_t)k * d.tile_w * d.tile_h + b * 64u + (ly & 7u) * 8u + (lx & 7u);
-      const size_t at = (size_t)sm * pix_work + w;
-      for (int c = 0; c < 3; c++) out_rgb[3 * i + c] = h_col[3 * at + c];
-      for (int c = 0; c < 4; c++) out_info[4 * i + c] = h_trace[4 * at + c];
-    }
-    return RTG_OK;
-  }
-  DevBuf<uint32_t> dx, dy, ds, dinfo;
-  DevBuf<float> drgb;
-  HIP_TRY(dx.alloc(n));
-  HIP_TRY(dy.alloc(n));
-  HIP_TRY(ds.alloc(n));
-  HIP_TRY(dinfo.alloc(4 * n));
-  HIP_TRY(drgb.alloc(3 * n));
-  HIP_TRY(hipMemcpy(dx.p, xs, n * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dy.p, ys, n * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(ds.p, samples, n * 4, hipMemcpyHostToDevice));
-  DevCamera cam = to_dev(camera);
-  dim3 grid((uint32_t)((n + 63) / 64)), block(64);
-  if (n) {
-    if (s->features & FEAT_DEEP)
-      hipLaunchKernelGGL((debug_samples_kernel<FEAT_ALL | FEAT_DEEP>), grid, block, 0, 0, s->dev, cam, d, (uint32_t)n, dx.p, dy.p, ds.p,
-                         drgb.p, dinfo.p);
-    else if (s->features == 0)
-      hipLaunchKernelGGL((debug_samples_kernel<0u>), grid, block, 0, 0, s->dev, cam, d, (uint32_t)n, dx.p, dy.p, ds.p,
-                         drgb.p, dinfo.p);
-    else
-      hipLaunchKernelGGL((debug_samples_kernel<FEAT_ALL>), grid, block, 0, 0, s->dev, cam, d, (uint32_t)n, dx.p, dy.p,
-                         ds.p, drgb.p, dinfo.p);
-  }
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out_rgb, drgb.p, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(out_info, dinfo.p, 4 * n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  return RTG_OK;
-}
-
-int rtg_tonemap_device(int device, size_t n, const float* d_rgb, uint8_t* d_out, void* hip_stream) {
-  if (!d_rgb || !d_out) return fail(RTG_ERR_INVALID, "null argument");
-  HIP_TRY(hipSetDevice(device));
-  if (n) hipLaunchKernelGGL(tonemap_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, n, d_rgb, d_out);
-  HIP_TRY(hipGetLastError());
-  return RTG_OK;
-}
-
-int rtg_tonemap(int device, size_t n, const float* rgb, uint8_t* out) {
-  if (!rgb || !out) return fail(RTG_ERR_INVALID, "null argument");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(RTG_ERR_DEVICE, "no HIP device");
-  HIP_TRY(hipSetDevice(device));
-  DevBuf<float> di;
-  DevBuf<uint8_t> dout;
-  HIP_TRY(di.alloc(n));
-  HIP_TRY(dout.alloc(n));
-  HIP_TRY(hipMemcpy(di.p, rgb, n * sizeof(float), hipMemcpyHostToDevice));
-  int rc = rtg_tonemap_device(device, n, di.p, dout.p, nullptr);
-  if (rc) return rc;
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out, dout.p, n, hipMemcpyDeviceToHost));
-  return RTG_OK;
-}
-
-int rtg_debug_flatten(rtg_builder* b, const rtg_id* world, size_t n, uint32_t* n_instructions, uint32_t* features,
-                      uint32_t* words_out, size_t capacity) {
-  if (!b || (!world && n)) return fail(RTG_ERR_INVALID, "null argument");
-  FlatScene fs;
-  try {
-    b->sb.flatten(world, n, &fs);
-  } catch (const BuildError& e) {
-    return fail(e.code, e.msg);
-  }
-  if (n_instructions) *n_instructions = (uint32_t)fs.lo.size();
-  if (features) *features = fs.features;
-  if (words_out) {
-    size_t m = fs.lo.size() < capacity ? fs.lo.size() : capacity;
-    for (size_t i = 0; i < m; i++) {
-      std::memcpy(words_out + 8 * i, fs.lo[i].w, 16);
-      std::memcpy(words_out + 8 * i + 4, fs.hi[i].w, 16);
-    }
-  }
-  return RTG_OK;
-}
-
-int rtg_debug_math(int device, int op, size_t n, const float* in, const float* in2, float* out) {
-  if (!in || !out || op < 0 || op > 5 || (op == 5 && !in2)) return fail(RTG_ERR_INVALID, "bad argument");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(RTG_ERR_DEVICE, "no HIP device");
-  HIP_TRY(hipSetDevice(device));
-  DevBuf<float> di, di2, dout;
-  HIP_TRY(di.alloc(n));
-  HIP_TRY(di2.alloc(n));
-  HIP_TRY(dout.alloc(n));
-  HIP_TRY(hipMemcpy(di.p, in, n * sizeof(float), hipMemcpyHostToDevice));
-  if (in2) HIP_TRY(hipMemcpy(di2.p, in2, n * sizeof(float), hipMemcpyHostToDevice));
-  if (n) hipLaunchKernelGGL(debug_math_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, op, n, di.p, di2.p, dout.p);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out, dout.p, n * sizeof(float), hipMemcpyDeviceToHost));
-  return RTG_OK;
-}
+#include "rtg_probes.inc"
 
 }  // extern "C"
