@@ -36,3 +36,20 @@ def test_current_profiles_name_existing_files(pkg):
     cur = json.load(open(os.path.join(ROOT, "profiles", "current.json")))
     for k, rel in cur.items():
         assert os.path.exists(os.path.join(ROOT, rel)), (k, rel)
+
+
+def test_current_profiles_belong_to_this_build(pkg):
+    """The counters profiles/current.json points at were collected on THIS tree's kernel sources (else bench.py reports
+    roofline.frac = null with the reason).  A kernel edit makes them stale until tools/collect_profiles.sh has run again on
+    the GPU box: that is reported as a skip here, not as a failure -- the round's last commit has to pass it."""
+    import json
+    import pytest
+    from rtiow_rust_amd import roofline as rl
+    cur = json.load(open(os.path.join(ROOT, "profiles", "current.json")))
+    stale = {}
+    for k, rel in cur.items():
+        why = rl.profile_staleness(rl.load_pmc(os.path.join(ROOT, rel)), ROOT)
+        if why:
+            stale[k] = why
+    if stale:
+        pytest.skip("stale counter profiles (re-run tools/collect_profiles.sh): %s" % stale)
