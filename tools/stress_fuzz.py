@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """More random object graphs than the test-suite holds (GPU box): GPU (instrumented and timed variant) against the oracle, bits and
-counters.  usage: stress_fuzz.py <first seed> <last seed>   [FZ_NX / FZ_NY / FZ_NS = frame size and samples]"""
+counters.  usage: stress_fuzz.py <first seed> <last seed>   [FZ_NX / FZ_NY / FZ_NS = frame size and samples; FZ_DEEP=1: every
+third graph is drawn with the shapes only the general walk handles (FEAT_DEEP)]"""
 import sys, os
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np
@@ -12,11 +13,12 @@ import time
 t0 = time.time()
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     gb = bool(seed % 4 == 0)
+    deep = os.environ.get("FZ_DEEP") == "1" and seed % 3 == 0
     imgs = []
     for be in (gpu, ora):
         rs = np.random.RandomState(seed)
         b = be.builder()
-        w = random_world(pkg, b, rs, general_boundaries=gb)
+        w = random_world(pkg, b, rs, general_boundaries=gb or deep, deep_shapes=deep)
         cam = random_camera(pkg, be, rs, int(os.environ.get("FZ_NX", "64")), int(os.environ.get("FZ_NY", "40")))
         sc = b.scene(w)
         if be is gpu:
