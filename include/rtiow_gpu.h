@@ -158,9 +158,11 @@ int rtg_par_cast(rtg_scene* s, const rtg_camera* camera, const rtg_params* param
                  rtg_stats* stats_or_null);
 /* Same, but out_rgb is DEVICE memory on the scene's device and the kernel is enqueued on
  * `hip_stream` (a hipStream_t, NULL = default stream).  Asynchronous unless stats are requested
- * (stats need the kernel to finish).  A scene handle allows ONE frame in flight: it owns the launch's work-queue
- * counter and scratch buffers and may re-grow them on the next call -- wait for the previous frame of the same handle
- * (or use a second handle) before calling again. */
+ * (stats need the kernel to finish).  Frames in flight: a handle owns a ring of launch contexts (work-queue counter,
+ * launch constants, cost-ordered queue, scratch, path slots; scene option "frames_in_flight" = 1..4, default 1).  A call
+ * takes the next context and first WAITS (on the host) for the frame that used it last, so back-to-back asynchronous calls
+ * on one handle are always safe -- with one context they serialise, with n they overlap up to n frames (on different
+ * streams).  Each context keeps its own scratch (12 B per pixel and sample up to the budget). */
 int rtg_par_cast_device(rtg_scene* s, const rtg_camera* camera, const rtg_params* params,
                         float* d_out_rgb, void* hip_stream, rtg_stats* stats_or_null);
 

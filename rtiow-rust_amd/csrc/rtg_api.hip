@@ -52,6 +52,29 @@ struct rtg_builder {
   SceneBuilder sb;
 };
 
+// Everything ONE frame in flight owns: work-queue head and statistics, launch constants, cost-ordered queue, per-sample scratch,
+// path slots / stacks, timing events.  A scene handle keeps a ring of these (option frames_in_flight, default 1); a call takes
+// the next one and first waits for the frame that used it last (`done`), so asynchronous calls on one handle are always safe
+// and, with more than one context, overlap.
+constexpr int RTG_MAX_FRAMES = 4;
+struct LaunchCtx {
+  unsigned long long* d_counters = nullptr;  // [0..4] N/P/H/rays/draws, [7] = work-queue head (persistent kernel), [8..] schedule statistics
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr;
+  bool busy = false;            // `done` was recorded and not waited for yet
+  float* d_stack = nullptr;     // full-feature pool kernel: per-wave transform stacks
+  size_t stack_bytes = 0;
+  uint32_t* d_slots = nullptr;  // ray-pool path slots when they live in global memory
+  size_t slots_bytes = 0;
+  float* d_scratch = nullptr;   // per-sample colours (sample passes: rtg_launch.inc)
+  size_t scratch_bytes = 0;
+  LaunchConsts* d_consts = nullptr;  // camera / frame parameters / chunk description of the launch (rt_pool.h), written on the launch stream
+  uint32_t* d_lpt = nullptr;    // cost-ordered work queue (rt_pool.h LptQueue)
+  size_t lpt_bytes = 0;
+  LptQueue lpt_desc{};          // descriptor of the last launch (RTG_VERBOSE histogram)
+  int last_kernel = 0;          // what launch_render chose last: 1 = baseline, 3 = lean ray pools, 4 = full-feature ray pools
+  uint32_t last_pix_work = 0;   // pixel work items of that launch (tiles x tile area), 0 when it kept no per-sample scratch
+};
+
 struct rtg_scene {
   int device = 0;
   DevScene dev{};
@@ -59,27 +82,13 @@ struct rtg_scene {
   uint32_t n_prog = 0, n_mat = 0, n_tex = 0;
   uint64_t bytes = 0;
   void* buffers[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  unsigned long long* d_counters = nullptr;  // [0..4] N/P/H/rays/draws, [7] = work-queue head (persistent kernel)
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t own_stream = nullptr;  // rtg_par_cast_multi: this scene's launch stream (created on first use)
   int num_cus = 0;
   float* d_frame = nullptr;     // rtg_par_cast: device staging frame for host framebuffers
   size_t frame_bytes = 0;
-  float* d_stack = nullptr;     // full-feature pool kernel: per-wave transform stacks
-  size_t stack_bytes = 0;
-  uint32_t* d_slots = nullptr;  // ray-pool path slots when they live in global memory
-  size_t slots_bytes = 0;
-  float* d_scratch = nullptr;  // chunk-mode per-sample colours
-  size_t scratch_bytes = 0;
   int force_chunks = 0;        // RTG_CHUNKS: 0 = automatic
   uint64_t scratch_limit = 0;  // option scratch_mb: budget of the per-sample colour scratch in bytes, 0 = half of the free HBM
   bool whole_scratch = false;  // the kernel trace reads every sample colour back: one pass regardless of the budget
-  LaunchConsts* d_consts = nullptr;  // camera / frame parameters / chunk description of the launch (rt_pool.h), written on the launch stream
-  uint32_t* d_lpt = nullptr;   // cost-ordered work queue (rt_pool.h LptQueue)
-  size_t lpt_bytes = 0;
-  LptQueue lpt_desc{};         // descriptor of the last launch (RTG_VERBOSE histogram)
-  int last_kernel = 0;         // what launch_render chose last: 1 = baseline, 3 = lean ray pools, 4 = full-feature ray pools
-  uint32_t last_pix_work = 0;  // pixel work items of that launch (tiles x tile area), 0 when it kept no per-sample scratch
   int verbose = 0;
   int window = -1;             // full-feature kernel: records of the program staged in LDS (-1 = as many as fit)
   int ray_lds = 1;             // 0: all slot fields in global memory
@@ -100,7 +109,36 @@ struct rtg_scene {
   int wg_per_cu = 0;                       // 0 = ask the occupancy API
   int full_threads = 0;                    // full-feature pool kernel: 0 = the variant's maximum (RTG_BLOCK overrides)
   int pool_threads = 1024;                 // lean ray-pool kernel: ONE 16-wave workgroup per CU shares one LDS copy of the program
+  LaunchCtx ctx[RTG_MAX_FRAMES];           // frames in flight
+  int n_ctx = 1, next_ctx = 0;
+  LaunchCtx* cx = &ctx[0];                 // the context of the call being made (ctx_acquire)
 };
+
+// Take the next launch context of the ring: create its small buffers on first use, wait for the frame that used it last.
+static int ctx_acquire(rtg_scene* s) {
+  LaunchCtx* c = &s->ctx[s->next_ctx];
+  s->next_ctx = (s->next_ctx + 1) % s->n_ctx;
+  if (!c->d_counters) {
+    if (hipMalloc((void**)&c->d_counters, 32 * sizeof(unsigned long long)) != hipSuccess || hipMemset(c->d_counters, 0, 32 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void**)&c->d_consts, sizeof(LaunchConsts)) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
+        hipEventCreate(&c->ev1) != hipSuccess || hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess)
+      return fail(RTG_ERR_DEVICE, "scene: launch-context allocation failed");
+  }
+  if (c->busy) {
+    hipError_t e = hipEventSynchronize(c->done);
+    c->busy = false;
+    if (e != hipSuccess) return hip_fail(e, "hipEventSynchronize(previous frame of this launch context)");
+  }
+  s->cx = c;
+  return RTG_OK;
+}
+// ... and mark it in flight on `stream` once its work is enqueued
+static int ctx_release(rtg_scene* s, hipStream_t stream) {
+  hipError_t e = hipEventRecord(s->cx->done, stream);
+  if (e != hipSuccess) return hip_fail(e, "hipEventRecord(done)");
+  s->cx->busy = true;
+  return RTG_OK;
+}
 
 #include "rtg_launch.inc"
 
@@ -367,15 +405,19 @@ void rtg_scene_destroy(rtg_scene* s) {
   (void)hipSetDevice(s->device);
   for (void* p : s->buffers)
     if (p) (void)hipFree(p);
-  if (s->d_counters) (void)hipFree(s->d_counters);
-  if (s->d_scratch) (void)hipFree(s->d_scratch);
-  if (s->d_slots) (void)hipFree(s->d_slots);
-  if (s->d_stack) (void)hipFree(s->d_stack);
-  if (s->d_lpt) (void)hipFree(s->d_lpt);
-  if (s->d_consts) (void)hipFree(s->d_consts);
+  for (LaunchCtx& c : s->ctx) {
+    if (c.busy) (void)hipEventSynchronize(c.done);
+    if (c.d_counters) (void)hipFree(c.d_counters);
+    if (c.d_scratch) (void)hipFree(c.d_scratch);
+    if (c.d_slots) (void)hipFree(c.d_slots);
+    if (c.d_stack) (void)hipFree(c.d_stack);
+    if (c.d_lpt) (void)hipFree(c.d_lpt);
+    if (c.d_consts) (void)hipFree(c.d_consts);
+    if (c.ev0) (void)hipEventDestroy(c.ev0);
+    if (c.ev1) (void)hipEventDestroy(c.ev1);
+    if (c.done) (void)hipEventDestroy(c.done);
+  }
   if (s->d_frame) (void)hipFree(s->d_frame);
-  if (s->ev0) (void)hipEventDestroy(s->ev0);
-  if (s->ev1) (void)hipEventDestroy(s->ev1);
   if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
   delete s;
 }
@@ -439,11 +481,11 @@ int rtg_scene_create(rtg_builder* b, const rtg_id* world, size_t n, int device, 
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->num_cus = prop.multiProcessorCount;
   if (s->num_cus <= 0) s->num_cus = 256;
-  if (hipMalloc((void**)&s->d_counters, 32 * sizeof(unsigned long long)) != hipSuccess || hipMalloc((void**)&s->d_consts, sizeof(LaunchConsts)) != hipSuccess ||
-      hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
+  if ((rc = ctx_acquire(s))) {  // the first launch context now: a scene that cannot allocate it is no scene
     rtg_scene_destroy(s);
-    return fail(RTG_ERR_DEVICE, "scene: counter/event allocation failed");
+    return rc;
   }
+  s->next_ctx = 0;
   *out = s;
   return RTG_OK;
 }
@@ -469,6 +511,10 @@ int rtg_scene_set_option(rtg_scene* s, const char* name, int value) {
     if (value && pool_lds_bytes(s->wide_bytes, s->n_mat, (uint32_t)s->pool_threads / 64u, true, false) > 160 * 1024)
       return fail(RTG_ERR_INVALID, "bvh4: the 4-wide image does not fit a CU's 160 KB of LDS (the 4-wide walk only exists LDS-staged)");
     s->bvh4 = value;
+  }
+  else if (k == "frames_in_flight") {  // launch contexts of this handle: asynchronous rtg_par_cast_device calls overlap up to this many frames
+    if (value < 1 || value > RTG_MAX_FRAMES) return fail(RTG_ERR_INVALID, "frames_in_flight: 1 .. 4");
+    s->n_ctx = value, s->next_ctx = 0;
   }
   else if (k == "force_rccl") s->force_rccl = value;
   else if (k == "sync") s->sync_full = value;
@@ -557,35 +603,37 @@ int rtg_par_cast_device(rtg_scene* s, const rtg_camera* camera, const rtg_params
   if (stats && stats->struct_size != sizeof(rtg_stats)) return fail(RTG_ERR_INVALID, "rtg_stats.struct_size mismatch");
   HIP_TRY(hipSetDevice(s->device));
   hipStream_t stream = (hipStream_t)hip_stream;
+  if ((rc = ctx_acquire(s))) return rc;
   DevCamera cam = to_dev(camera);
   bool count = stats && (params->flags & RTG_FLAG_COUNTERS);
   if (count) {
-    HIP_TRY(hipMemsetAsync(s->d_counters, 0, 7 * sizeof(unsigned long long), stream));
-    HIP_TRY(hipMemsetAsync(s->d_counters + 8, 0, 24 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(s->cx->d_counters, 0, 7 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(s->cx->d_counters + 8, 0, 24 * sizeof(unsigned long long), stream));
   }
-  if (stats) HIP_TRY(hipEventRecord(s->ev0, stream));
+  if (stats) HIP_TRY(hipEventRecord(s->cx->ev0, stream));
   HIP_TRY(count ? launch_render<true>(s, cam, d, d_out, stream) : launch_render<false>(s, cam, d, d_out, stream));
+  if ((rc = ctx_release(s, stream))) return rc;
   if (stats) {
-    HIP_TRY(hipEventRecord(s->ev1, stream));
-    HIP_TRY(hipEventSynchronize(s->ev1));
+    HIP_TRY(hipEventRecord(s->cx->ev1, stream));
+    HIP_TRY(hipEventSynchronize(s->cx->ev1));
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    HIP_TRY(hipEventElapsedTime(&ms, s->cx->ev0, s->cx->ev1));
     stats->kernel_ms = ms;
     stats->samples = owned_pixels(d) * d.ns;
     unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (count) HIP_TRY(hipMemcpy(h, s->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+    if (count) HIP_TRY(hipMemcpy(h, s->cx->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     stats->aabb_tests = h[0], stats->prim_tests = h[1], stats->shaded_hits = h[2], stats->rays = h[3], stats->draws = h[4];
-    if (count && s->verbose && s->lpt_desc.n_blocks && s->d_lpt) {  // cost classes of the last frame (class 0 = deepest)
+    if (count && s->verbose && s->cx->lpt_desc.n_blocks && s->cx->d_lpt) {  // cost classes of the last frame (class 0 = deepest)
       std::vector<uint32_t> ctl(LPT_CTL);
-      HIP_TRY(hipMemcpy(ctl.data(), s->lpt_desc.ctl, LPT_CTL * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(ctl.data(), s->cx->lpt_desc.ctl, LPT_CTL * sizeof(uint32_t), hipMemcpyDeviceToHost));
       std::string line;
       for (uint32_t c = 0; c < LPT_CLASSES; c++)
         if (ctl[c]) line += " " + std::to_string(c) + ":" + std::to_string(ctl[c]);
-      fprintf(stderr, "[rtg] cost-ordered queue: %u of %u blocks filed, class:blocks%s\n", ctl[LPT_CLASSES], s->lpt_desc.n_blocks, line.c_str());
+      fprintf(stderr, "[rtg] cost-ordered queue: %u of %u blocks filed, class:blocks%s\n", ctl[LPT_CLASSES], s->cx->lpt_desc.n_blocks, line.c_str());
     }
     if (count && s->verbose) {
       unsigned long long q[24];
-      HIP_TRY(hipMemcpy(q, s->d_counters + 8, sizeof(q), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(q, s->cx->d_counters + 8, sizeof(q), hipMemcpyDeviceToHost));
       if (q[18]) {  // lean pool kernel: per-wave timeline, scaled so that the longest wave = the measured kernel time
         const double us = (double)ms * 1000. / (double)q[16], n = (double)q[18];
         fprintf(stderr, "[rtg] wave timeline (us from its start): sees the work queue empty at min %.0f / mean %.0f / max %.0f; done at mean %.0f / max %.0f\n",
@@ -598,7 +646,7 @@ int rtg_par_cast_device(rtg_scene* s, const rtg_camera* camera, const rtg_params
               q[2] ? (double)q[11] / q[2] : 0.);
       if (q[15]) {  // full-feature pool kernel: the steps of a service
         unsigned long long f[2];
-        HIP_TRY(hipMemcpy(f, s->d_counters + 5, sizeof(f), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(f, s->cx->d_counters + 5, sizeof(f), hipMemcpyDeviceToHost));
         fprintf(stderr, "[rtg] services %llu: finish step %.1f%% of wave time (%.0f ticks each), refill step %.1f%% (%.0f ticks per refill)\n", f[0],
                 100 * f[1] / tt, f[0] ? (double)f[1] / f[0] : 0., 100 * q[15] / tt, q[6] ? (double)q[15] / q[6] : 0.);
       }

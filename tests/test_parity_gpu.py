@@ -263,6 +263,53 @@ def test_bounded_sample_scratch_renders_in_passes(pkg, gpu, oracle, name, nx, ny
     assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns), ref, name + " (one pass again)")
 
 
+@pytest.mark.parametrize("frames", [1, 3])
+def test_frames_in_flight_on_one_handle(pkg, gpu, oracle, frames):
+    """rtg_par_cast_device is asynchronous; round 2 allowed ONE frame in flight per handle and left the rest to the caller.
+    Now a handle owns a ring of launch contexts: six frames (several seeds and sample counts) enqueued back to back on three
+    streams WITHOUT any wait in between must all equal the oracle's, with one context (the calls serialise on the host) and
+    with three (they overlap), on the lean and on the full-feature pool kernel.  (Device buffers and streams straight from
+    the HIP runtime the library itself uses: no second runtime in the process.)"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipFree.argtypes = [C.c_void_p]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    for name, nx, ny in (("book1", 160, 96), ("book2", 96, 96)):
+        sg, cam_g, _, _, _ = build_case(pkg, gpu, name, nx, ny)
+        so, cam_o, _, _, _ = build_case(pkg, oracle, name, nx, ny)
+        sg.set_option("frames_in_flight", frames)
+        streams = []
+        for _ in range(3):
+            st = C.c_void_p()
+            assert hip.hipStreamCreate(C.byref(st)) == 0
+            streams.append(st)
+        jobs = [(7, 0xDEADBEEF), (20, 0xDEADBEEF), (3, 1234), (12, 99), (7, 5), (33, 0xDEADBEEF)]
+        nbytes = nx * ny * 3 * 4
+        outs = []
+        for _ in jobs:
+            d = C.c_void_p()
+            assert hip.hipMalloc(C.byref(d), nbytes) == 0
+            outs.append(d)
+        assert hip.hipDeviceSynchronize() == 0
+        for k, (ns, seed) in enumerate(jobs):
+            p = pkg.make_params(nx, ny, ns, seed=seed)
+            sg.par_cast_device(cam_g, p, outs[k], streams[k % 3])
+        assert hip.hipDeviceSynchronize() == 0
+        for k, (ns, seed) in enumerate(jobs):
+            img = np.empty((ny, nx, 3), dtype=np.float32)
+            assert hip.hipMemcpy(img.ctypes.data_as(C.c_void_p), outs[k], nbytes, 2) == 0   # hipMemcpyDeviceToHost
+            assert_bit_equal(img, so.par_cast(cam_o, nx, ny, ns, seed=seed), "%s frame %d (%d contexts)" % (name, k, frames))
+        for d in outs:
+            hip.hipFree(d)
+        for st in streams:
+            hip.hipStreamDestroy(st)
+    with pytest.raises(pkg.RtError):
+        sg.set_option("frames_in_flight", 9)
+
+
 def test_ragged_image_sizes(pkg, gpu, oracle):
     """Sizes that are not multiples of the 16x16 block / 8x8 wave tile, and 1-pixel images."""
     for (nx, ny) in [(1, 1), (17, 9), (33, 47), (15, 64)]:
