@@ -231,6 +231,15 @@ fn params(nx: usize, ny: usize, ns: usize, o: &CastOptions) -> sys::rtg_params {
 }
 
 impl GpuScene {
+    /// Scheduling / resource switches of this handle (`rtg_scene_set_option`; none changes a bit of the result): e.g.
+    /// `("scratch_mb", 4096)` bounds the per-sample colour scratch (larger frames render in sample passes),
+    /// `("frames_in_flight", 2)` lets two asynchronous frames of this handle overlap, `("force_rccl", 1)` sends
+    /// `gpu_cast_multi` through the RCCL collective even on one device.
+    pub fn set_option(&mut self, name: &str, value: i32) -> Result<()> {
+        let c = std::ffi::CString::new(name).map_err(|_| last_error(sys::RTG_ERR_INVALID))?;
+        check(unsafe { sys::rtg_scene_set_option(self.raw, c.as_ptr(), value) })
+    }
+
     /// par_cast (lib.rs:363) on this scene's GPU.
     pub fn par_cast(&mut self, nx: usize, ny: usize, ns: usize, camera: &Camera, options: &CastOptions) -> Result<Image> {
         let mut rgb = vec![0f32; nx * ny * 3];
@@ -264,6 +273,14 @@ pub fn gpu_cast_multi<W: FlattenWorld + ?Sized>(nx: usize, ny: usize, ns: usize,
     let p = params(nx, ny, ns, &CastOptions::default());
     check(unsafe { sys::rtg_par_cast_multi(raws.as_ptr(), raws.len() as i32, &camera.0, &p, rgb.as_mut_ptr(), ptr::null_mut()) })?;
     Ok(Image { nx, ny, rgb })
+}
+
+/// Forget the library's multi-GPU state: destroy the cached RCCL communicators, unload librccl (the next `gpu_cast_multi`
+/// loads it again).  Returns the number of `ncclReduce` calls issued since the last reset.
+pub fn multi_reset() -> Result<u64> {
+    let mut n = 0u64;
+    check(unsafe { sys::rtg_multi_reset(ptr::null(), &mut n) })?;
+    Ok(n)
 }
 
 pub fn device_count() -> Result<i32> {
