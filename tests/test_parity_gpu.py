@@ -516,14 +516,13 @@ def test_bench_multi_rank_path_on_one_gpu(tmp_path, scaling):
         assert 0.0 < line["roofline"]["frac"] <= 1.0
 
 
-def test_bench_gpus_flag_is_self_sufficient(tmp_path):
+def test_bench_gpus_flag_is_self_sufficient(tmp_path, gpu):
     """`python bench.py --gpus N` WITHOUT a launcher starts its own N ranks (torch.distributed.run, one per GPU) and reports
     n_gpus == N; it never reports another N than the one asked for: with fewer GPUs than ranks (RCCL: one rank per device)
     and with a WORLD_SIZE that contradicts --gpus it exits non-zero and prints no JSON line."""
     import json
     import subprocess
     import sys
-    import torch
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     bench = os.path.join(root, "bench.py")
     small = ["--steps", "1", "--warmup", "0", "--nx", "160", "--ny", "96", "--no-cpu-baseline"]
@@ -535,7 +534,7 @@ def test_bench_gpus_flag_is_self_sufficient(tmp_path):
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["verified_bit_exact_vs_unsharded"] is True
     # (b) more ranks than GPUs over RCCL: refused before anything is rendered
-    n_too_many = torch.cuda.device_count() + 7
+    n_too_many = gpu.device_count() + 7   # (no torch in THIS process: its first import can take minutes on a fresh box)
     out = subprocess.run([sys.executable, bench, "--gpus", str(n_too_many)] + small, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode != 0 and "GPU(s)" in out.stderr
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

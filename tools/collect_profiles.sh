@@ -24,5 +24,5 @@ python tools/criterion_scene.py > $O/criterion_scene.txt 2>&1
 tools/ubench/issue_rate > $O/issue_rate.txt 2>&1
 tools/ubench/mem_latency > $O/mem_latency.txt 2>&1
 python tools/libm_exhaustive_gpu.py > $O/libm_exhaustive_gpu.txt 2>&1
-python -m pytest tests -m gpu -q --timeout=120 > $O/pytest_gpu.log 2>&1
+python -m pytest tests -m gpu -q --timeout=300 > $O/pytest_gpu.log 2>&1
 ls -la $O
