@@ -132,6 +132,9 @@ def main():
                          "book2: 5000 spp = C5); 'weak' renders N x the N = 1 spp (per-GPU samples fixed)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xDEADBEEF)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true",
+                    help="N = 1 default run: skip the secondary anchors (north_star's 1200x800x500 frame = C3's, and C4 "
+                         "book-2 800x800x1000) that are timed in the same process after the headline loop")
     ap.add_argument("--verify", action="store_true",
                     help="rank 0 also renders the frame unsharded and checks the reduced frame bit-for-bit")
     args = ap.parse_args()
@@ -241,6 +244,32 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # Secondary anchors of the default N = 1 run, timed in this process AFTER the headline loop (they cannot disturb it):
+    # the frame north_star's target names (C3's 1200x800x500, here on ONE GPU: what `--gpus 2/4/8` is compared against) and
+    # C4.  Same step definition (one par_cast into an HBM-resident framebuffer, barrier-free at N = 1, synchronised both sides).
+    also = None
+    default_run = (world == 1 and args.workload == "book1" and not args.bvh4 and args.bvh == "reference" and not args.spp
+                   and (nx, ny) == (wnx, wny))
+    if default_run and not args.no_also:
+        def anchor(wl, a_spp, a_steps):
+            a_build, anx, any_, _, _, _ = WORKLOADS[wl]
+            ab = gpu.builder()
+            a_objs, a_cam, _ = a_build(pkg, ab, anx, any_)
+            a_scene = ab.scene(a_objs, device=dev_index)
+            a_fb = torch.zeros((any_, anx, 3), dtype=torch.float32, device=dev)
+            a_p = pkg.make_params(anx, any_, a_spp, seed=args.seed)
+            one = lambda: a_scene.par_cast_device(a_cam, a_p, ctypes.c_void_p(a_fb.data_ptr()), stream, want_stats=True)  # noqa: E731
+            one()
+            torch.cuda.synchronize()
+            a_t0 = time.perf_counter()
+            k_ms = [one()["kernel_ms"] for _ in range(a_steps)]
+            torch.cuda.synchronize()
+            a_dt = (time.perf_counter() - a_t0) / a_steps
+            return {"value": anx * any_ * a_spp / a_dt / 1e6, "unit": "Msamples/s", "ms_per_step": a_dt * 1e3,
+                    "kernel_ms_avg": sum(k_ms) / len(k_ms), "steps": a_steps, "warmup": 1}
+        also = {"book1_random_spheres_1200x800x500spp": dict(anchor("book1", 500, 5), baseline_config="configs[2] on ONE GPU (north_star target frame)"),
+                "book2_final_scene_800x800x1000spp": dict(anchor("book2", 1000, 3), baseline_config="configs[3]")}
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         total_samples = nx * ny * spp
@@ -255,11 +284,11 @@ def main():
         kernel_name = {"book1": "rtg::render_lean_pool", "book2": "rtg::render_full_pool", "cornell": "rtg::render_full_sync"}[args.workload]
         kernel_s = avg_kernel_ms * 1e-3
         rank_samples = px_rank * spp
-        pmc, pmc_path = rl.find_profile(ROOT, (args.workload if args.bvh == "reference" else args.workload + "_" + args.bvh) + ("_bvh4" if args.bvh4 else ""))
+        pmc, pmc_path = rl.find_profile(ROOT, (args.workload if args.bvh == "reference" else args.workload + "_" + args.bvh) + ("_bvh4" if args.bvh4 else ""), spp)
         if pmc is not None:
             # counters are only quoted for the build and schedule they were collected on (profiles carry the git blob hashes
-            # of csrc/*): another build -> achieved / frac = null + the reason
-            knobs = sorted(k for k in os.environ if k.startswith("RTG_") and k != "RTG_BENCH_BACKEND" and os.environ[k] != pmc.get("env_options", {}).get(k))
+            # of csrc/*): another build, or an RTG_* option set on one side only -> achieved / frac = null + the reason
+            knobs = rl.knob_differences(pmc, os.environ)
             stale = rl.profile_staleness(pmc, ROOT, lib_override=os.environ.get("RTIOW_GPU_LIB"), knobs=knobs)
             if stale is None and (nx, ny) != (wnx, wny):
                 stale = "frame geometry %dx%d differs from the profiled %dx%d" % (nx, ny, wnx, wny)
@@ -267,8 +296,8 @@ def main():
             roof["pmc_source"] = pmc_path
             roof["pmc_build"] = pmc.get("build", {}).get("digest")
         else:   # no counter profile for this workload: the contract's keys with the unmeasured ones null
-            roof = {"bound": "valu", "achieved": None, "peak": rl.N_CUS * rl.SIMDS_PER_CU * rl.NOMINAL_CLOCK_HZ / rl.ISSUE_CYCLES / 1e9,
-                    "unit": "G wave-instructions/s", "frac": None, "traffic": None}
+            roof = {"bound": "valu", "achieved": None, "peak": rl.N_CUS * rl.SIMDS_PER_CU * 64 * rl.NOMINAL_CLOCK_HZ / rl.ISSUE_CYCLES / 1e9,
+                    "unit": "G lane-instructions/s", "frac": None, "traffic": None}
         roof.update({
             "kernel": kernel_name + " (+ rtg::fold_samples_kernel, ~1%): HIP events around both on the launch stream",
             "kernel_ms_avg": avg_kernel_ms,
@@ -309,6 +338,8 @@ def main():
             },
             "roofline": roof,
         }
+        if also is not None:
+            line["also"] = also
         if verified is not None:
             line["verified_bit_exact_vs_unsharded"] = verified
         if world == 1 and not args.no_cpu_baseline:

@@ -13,6 +13,8 @@
 //   Bvh leaf                        -> BOX{aabb, skip}, object's stream              instr. after)
 //   Translate/Scale/RotateY/LinearMove/FlipNormals over a subtree -> PUSH, subtree, POP
 //   Sphere, Translate{Sphere}, FlipNormals thereof -> one fused SPHERE record
+//   LinearMove{Sphere}, Translate{LinearMove{Sphere}} (main.rs:218-229), FlipNormals thereof -> one fused SPHERE record with
+//                                                     F_MOVE + one data record (OP_EXT: the motion vector) behind it
 //   Rect<A>, FlipNormals(Rect<A>)                  -> one RECT record
 //   rect_prism(p0, p1, m) (the exact And-tree of object.rs:420-473) -> one PRISM record
 //   Translate{RotateY{x}}, Translate{LinearMove{x}} -> ONE PUSH/POP pair (F_PRE_TRANSLATE): same arithmetic, in sequence
@@ -43,6 +45,8 @@ enum Op : uint32_t {
                   //      runs the boundary's stream as a range query (rt_pool_full.h GENB) finishes the query here.
   // Only in programs with FEAT_DEEP (graph shapes the scheduled kernels do not walk; the general walk of rt_trace.h does):
   OP_SAVE = 9,    // in front of the stream of an `And` that sits below a Bvh and holds a ConstantMedium: remember the hit so far
+  OP_EXT = 11,    // data-only continuation of the record in front of it (a SPHERE with F_MOVE: lo = motion.xyz); never executed:
+                  // the record that owns it steps over it
   OP_MERGE = 10,  // behind it: bvh.rs:104-112 for that leaf -- the earlier hit `hl` wins when hl.t < hr.t (only a medium can
                   // return t >= t_range.end; inside the And itself the later hit replaces, object.rs:403-409)
 };
@@ -58,6 +62,9 @@ constexpr uint32_t F_GATHER = 1u << 15;     // any non-BOX record: head of a run
                                             // hint: every ray passes here and then executes the same records in the same order)
 constexpr uint32_t F_MATKIND_SHIFT = 16;    // SPHERE/RECT/MEDIUM: bits 16-18 = MatKind of the record's material (copy, for schedulers)
 constexpr uint32_t F_TEXTURED = 1u << 19;   // SPHERE/RECT/PRISM/MEDIUM: the material reads a checker / Perlin texture (copy, for schedulers)
+constexpr uint32_t F_MOVE = 1u << 20;      // SPHERE: a LinearMove sits between the (optional, F_TRANSLATE) Translate and the sphere: after the
+                                            // translate, origin -= time * motion (object.rs:505-508; nothing on the way out); motion = lo.xyz of the
+                                            // OP_EXT record behind this one, which the SPHERE steps over (pc += 2)
 constexpr uint32_t F_KIND_SHIFT = 8;        // PUSH/POP: bits 8-10 = XformKind
 constexpr uint32_t F_PRE_TRANSLATE = 1u << 11;  // PUSH/POP (RotateY / LinearMove): an enclosing Translate rides along,
                                                 // offset = (lo.w, hi.x, hi.y): applied first on the way in, last on the way out

@@ -70,6 +70,51 @@ RT_DEV T* uniform_ptr(T* p) {
 
 #define RT_TICK() (COUNT ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull)
 
+// Drain timeline (diagnostic builds only, -DRT_TIMELINE; tools/timeline.py): every wave of a pool kernel leaves one 16-dword
+// record in the buffer counters[31] points to -- s_memrealtime (the chip-wide 100 MHz clock) at its start [0], when it sees the
+// work queue empty [1], when its live paths fall to <= 64 [3] / <= 8 [10] / <= 1 [11], when it is done [4]; its live paths [2] and
+// list sizes [12..14] at exhaustion; after exhaustion: shade passes [5], services [6], shade passes that held a ray at bounce
+// >= 16 [7], rays handed to lanes [9], lanes of the shade passes [8].  Production builds compile none of it.
+#ifdef RT_TIMELINE
+#define RT_TL_NOW() ((uint32_t)__builtin_amdgcn_s_memrealtime())
+#define RT_TL_DECL(pool_) \
+  uint32_t* tl = nullptr; \
+  uint32_t tl_passes = 0, tl_serv = 0, tl_deep = 0, tl_rays = 0, tl_lanes = 0, tl_stage = 0; \
+  bool tl_deep_now = false; \
+  { const unsigned long long p_ = counters[31]; \
+    if (p_) tl = reinterpret_cast<uint32_t*>(p_) + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16u; } \
+  if (tl && (threadIdx.x & 63u) == 0u) tl[0] = RT_TL_NOW()
+#define RT_TL_EXHAUSTED(alive_, t_, s_, e_) \
+  if (tl && (threadIdx.x & 63u) == 0u) tl[1] = RT_TL_NOW(), tl[2] = (alive_), tl[12] = (t_), tl[13] = (s_), tl[14] = (e_)
+#define RT_TL_BOUNCES(b_) tl_deep_now = (b_) >= 16u
+#define RT_TL_SHADE(take_, m_live_) \
+  if (exhausted) { \
+    tl_passes++, tl_lanes += (take_); \
+    if (__builtin_amdgcn_ballot_w64(tl_deep_now && (threadIdx.x & 63u) < (take_)) != 0) tl_deep++; \
+  } \
+  tl_deep_now = false
+#define RT_TL_ALIVE(alive_) \
+  if (tl && exhausted) { \
+    const uint32_t a_ = (alive_); \
+    if (tl_stage < 1u && a_ <= 64u) { tl_stage = 1u; if ((threadIdx.x & 63u) == 0u) tl[3] = RT_TL_NOW(); } \
+    if (tl_stage < 2u && a_ <= 8u) { tl_stage = 2u; if ((threadIdx.x & 63u) == 0u) tl[10] = RT_TL_NOW(); } \
+    if (tl_stage < 3u && a_ <= 1u) { tl_stage = 3u; if ((threadIdx.x & 63u) == 0u) tl[11] = RT_TL_NOW(); } \
+  }
+#define RT_TL_REFILL(got_) if (exhausted) tl_rays += (got_)
+#define RT_TL_SERVICE() if (exhausted) tl_serv++
+#define RT_TL_DONE() \
+  if (tl && (threadIdx.x & 63u) == 0u) tl[4] = RT_TL_NOW(), tl[5] = tl_passes, tl[6] = tl_serv, tl[7] = tl_deep, tl[8] = tl_lanes, tl[9] = tl_rays
+#else
+#define RT_TL_DECL(pool_)
+#define RT_TL_EXHAUSTED(alive_, t_, s_, e_)
+#define RT_TL_BOUNCES(b_)
+#define RT_TL_SHADE(take_, m_live_)
+#define RT_TL_ALIVE(alive_)
+#define RT_TL_REFILL(got_)
+#define RT_TL_SERVICE()
+#define RT_TL_DONE()
+#endif
+
 
 #ifndef RT_UNIFORM_SLOT_PTR
 #define RT_UNIFORM_SLOT_PTR 1
@@ -362,6 +407,17 @@ RT_DEV uint4 fetch_hi_global(const DevScene& sc, uint32_t idx) {  // pc-scaled s
   return h;
 }
 
+// Continuing rays first.  The T-list is TWO stacks in one array: rays written by a SCATTER pass (paths that go on) grow from
+// position 0 upwards, camera rays of new paths (END pass) from the top downwards; a refill takes continuing rays first and
+// new ones only for the lanes that are left.  A path in flight never waits behind paths that have not begun: with ONE stack
+// the camera rays of every END pass buried the continuing rays below them until the list ran dry -- at the end of the frame
+// (profiles/r04_experiments/r04a_tl_*.txt: the last waves of a launch each finish one ~50-bounce chain alone, 1.6 lanes per
+// pass; on book-2 the bottom of the stack held piles of old deep paths that then ran as 64-wide batches one after another).
+// Measured (profiles/r04_experiments/r04b_*): book-1 unchanged (the chain that ends a launch began in one of the last blocks),
+// book-2 fixed cost 9.6 -> 8.9 ms but slope +3 % (camera rays of one 8x8 block no longer traverse together): off.
+#ifndef RT_T_PRIORITY
+#define RT_T_PRIORITY 0
+#endif
 #ifndef RT_SCATTER_TRIES
 #define RT_SCATTER_TRIES 4  // in_unit_sphere attempts per SCATTER pass and slot (0 = as many as the unluckiest lane needs)
 #endif
@@ -492,12 +548,14 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
 
   const float t_near = load_const(&lc->P.t_near);
   uint32_t t_count = 0, s_count = 0, e_count = POOL, n_dead = 0;  // wave-uniform list sizes / retired slots
+  uint32_t tn_count = 0;  // RT_T_PRIORITY: camera rays of new paths, stacked from the top of tlist downwards (t_count: continuing rays, from 0 upwards)
   uint32_t w_next = 0, w_end = 0;                                  // this wave's reserved range of work items
   uint32_t w_chunk = 0, w_delta = 0;                               // ... their chunk, and pixel work index - item index
   bool w_lpt_ready = false;
   bool exhausted = false;                                          // the global counter ran past total_work
   const unsigned long long t_start = RT_TICK();
   unsigned long long t_exhausted = 0;
+  RT_TL_DECL(POOL);
 
   // ---- per-lane traversal state ---------------------------------------------------------------
   uint32_t my_slot = 0;
@@ -616,7 +674,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
     // END are pushed (rays wait in S and E for company: "idle lanes" alone would call it after every step of a starved wave)
 #if RT_GATED_SERVICE
     const uint32_t n_fin = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op == OP_END));
-    const bool can_serve = t_count != 0u || s_count + n_fin >= 64u || e_count + n_fin >= 64u;
+    const bool can_serve = (t_count + tn_count) != 0u || s_count + n_fin >= 64u || e_count + n_fin >= 64u;
 #else
     const bool can_serve = true;
 #endif
@@ -641,7 +699,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
         s_count += (uint32_t)__builtin_popcountll(m_s);
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      const bool starving = (t_count == 0 && n_busy == 0);  // nothing to traverse: run partial passes too
+      const bool starving = (t_count + tn_count == 0 && n_busy == 0);  // nothing to traverse: run partial passes too
       // (2a) SCATTER pass: Material::scatter for 64 hits on scattering materials
       while (s_count >= 64u || (s_count > 0 && starving)) {
         const uint32_t take = s_count < 64u ? s_count : 64u;
@@ -662,6 +720,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           // the strength row is only valid from the first scatter on: a fresh path carries (1, 1, 1) (lib.rs:63) implicitly
           V3 strength = mk(SLOT_F(PF_STRENGTH, j), SLOT_F(PF_STRENGTH + 1, j), SLOT_F(PF_STRENGTH + 2, j));
           if (bounces == 0u) strength = splat(1.f);
+          RT_TL_BOUNCES(bounces);
           const uint32_t s = SLOT_U(PF_SAMPLE, j), xy = SLOT_U(PF_XY, j);
           const float hb = BEST_F(j);
           // ---------------- color() loop body, lib.rs:73-97, for a hit on a scattering material ----------
@@ -762,6 +821,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
         if (cm.lpt_samples) lpt_count(cm, lpt_on, lpt_blk);
         const uint64_t m_live = __builtin_amdgcn_ballot_w64(live), m_ended = __builtin_amdgcn_ballot_w64(ended);
         const uint64_t m_def = __builtin_amdgcn_ballot_w64(deferred);
+        RT_TL_SHADE(take, m_live);
         if (live) tlist[t_count + lane_rank(m_live)] = (uint16_t)j;
         if (ended) elist[e_count + lane_rank(m_ended)] = (uint16_t)j;
         if (deferred) slist[s_count + lane_rank(m_def)] = (uint16_t)j;  // (over entries this pass has already read)
@@ -772,7 +832,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
         if (COUNT) t_shade += RT_TICK() - t_mark2;
       }
       // (2b) END pass: book the sample colour, next work item, camera ray
-      while (e_count >= 64u || (e_count > 0 && starving && t_count == 0)) {
+      while (e_count >= 64u || (e_count > 0 && starving && t_count + tn_count == 0)) {
         const uint32_t take = e_count < 64u ? e_count : 64u;
         e_count -= take;
         if (COUNT) n_end++, n_end_lanes += take, t_mark2 = RT_TICK();
@@ -839,6 +899,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
             if (base >= total_work) {
               exhausted = true;
               if (COUNT) t_exhausted = RT_TICK();
+              RT_TL_EXHAUSTED(POOL - n_dead, t_count + tn_count, s_count, e_count);
             } else {
               if (cm.scratch) w_chunk = lpt_reservation(cm, base, lane, w_delta, w_lpt_ready);
               w_next = base;
@@ -886,21 +947,29 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           SLOT_U(PF_XY, j) = x | (row << 16);
         }
         const uint64_t m_live = __builtin_amdgcn_ballot_w64(live);
+#if RT_T_PRIORITY
+        if (live) tlist[POOL - 1u - (tn_count + lane_rank(m_live))] = (uint16_t)j;
+        tn_count += (uint32_t)__builtin_popcountll(m_live);
+#else
         if (live) tlist[t_count + lane_rank(m_live)] = (uint16_t)j;
         t_count += (uint32_t)__builtin_popcountll(m_live);
+#endif
         n_dead += take - (uint32_t)__builtin_popcountll(m_live);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         if (COUNT) t_shade += RT_TICK() - t_mark2;
+        RT_TL_ALIVE(POOL - n_dead);
       }
       // (3) refill idle lanes from the T-list
       {
         const uint64_t m_idle = __builtin_amdgcn_ballot_w64(!have_ray);
         const uint32_t n_idle = (uint32_t)__builtin_popcountll(m_idle);
-        const uint32_t got = n_idle < t_count ? n_idle : t_count;
+        const uint32_t t_all = t_count + tn_count;
+        const uint32_t got = n_idle < t_all ? n_idle : t_all;
         if (got) {
           const uint32_t r = lane_rank(m_idle);
+          const uint32_t take_c = got < t_count ? got : t_count;  // continuing rays first
           if (!have_ray && r < got) {
-            my_slot = tlist[t_count - 1u - r];
+            my_slot = r < take_c ? tlist[t_count - 1u - r] : tlist[POOL - tn_count + (r - take_c)];
             o = mk(RAY_F(PF_O, my_slot), RAY_F(PF_O + 1, my_slot), RAY_F(PF_O + 2, my_slot));
             d = mk(RAY_F(PF_D, my_slot), RAY_F(PF_D + 1, my_slot), RAY_F(PF_D + 2, my_slot));
             inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);  // aabb.rs:17
@@ -914,11 +983,13 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
             }
             have_ray = true;
           }
-          t_count -= got;
+          t_count -= take_c, tn_count -= got - take_c;
           if (COUNT) n_refill++, n_refill_lanes += got;
+          RT_TL_REFILL(got);
         }
       }
       if (COUNT) t_serv += RT_TICK() - t_mark;
+      RT_TL_SERVICE();
       if (n_dead == POOL) break;  // every slot retired: this wave is done
       if (__builtin_amdgcn_ballot_w64(have_ray) == 0) continue;  // nothing to traverse yet: service again
       op = have_ray ? (c_flags & 0xffu) : 0xffu;
@@ -986,6 +1057,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
     if (64u - busy >= tune.refill_min || busy == 0) break;
     }
   }
+  RT_TL_DONE();
   if (COUNT) {
     atomicAdd(&counters[0], (unsigned long long)cnt.aabb);
     atomicAdd(&counters[1], (unsigned long long)cnt.prim);

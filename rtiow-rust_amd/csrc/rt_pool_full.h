@@ -30,6 +30,12 @@ namespace rtg {
 #define RT_FULL_POOL_SLOTS 224  // 64 in the lanes + rays that wait for company in S, X and N (up to 63 each) + T to refill from;
                                 // book-2: 160 52.6 ms (the lanes starve), 192 45.3, 224 43.9, 256 44.6, 320 45.4
 #endif
+#ifndef RT_RUN_AHEAD_NOBOX
+#define RT_RUN_AHEAD_NOBOX 1  // rt_full_traverse.inc: a slow pass runs ahead while no lane waits at a BOX record
+#endif
+#ifndef RT_DRAIN_ALL
+#define RT_DRAIN_ALL 1  // a starved wave runs the partial passes of ALL its stacks before it refills
+#endif
 #ifndef RT_FULL_BOX_UNROLL
 #define RT_FULL_BOX_UNROLL 2  // box steps per schedule check (book-2 43.8 -> 43.0 ms)
 #endif
@@ -170,11 +176,13 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
 
   const float t_near = load_const(&lc->P.t_near);
   uint32_t t_count = 0, s_count = 0, x_count = 0, n_count = FPOOL, n_dead = 0;
+  uint32_t tn_count = 0;  // RT_T_PRIORITY (rt_pool.h): camera rays of new paths, stacked from position FPOOL - 1 of the T rows downwards
   uint32_t w_next = 0, w_end = 0, w_chunk = 0, w_delta = 0;
   bool w_lpt_ready = false;
   bool exhausted = false;
   const unsigned long long t_start = RT_TICK();
   unsigned long long t_exhausted = 0;
+  RT_TL_DECL(FPOOL);
 
   // ---- per-lane traversal state ---------------------------------------------------------------
   bool have_ray = false;
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
     // the lanes that stand at END are pushed.  (With rays waiting in S and X for company, "idle lanes" alone would call it
     // after every traversal step of a starved wave.)
     const uint32_t n_fin = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op == OP_END));
-    const bool can_serve = t_count != 0u || s_count + n_fin >= 64u || (TEX && x_count + n_fin >= 64u);
+    const bool can_serve = (t_count + tn_count) != 0u || s_count + n_fin >= 64u || (TEX && x_count + n_fin >= 64u);
     if ((64u - n_busy >= tune.refill_min && can_serve) || n_busy == 0) {
       if (COUNT) t_mark = RT_TICK();
       {  // (1) finish (depth is 0 again, so o / d are the ray's own)
@@ -265,6 +273,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           stime = SQ_LD_F(SQ_TIME, j);
           strength = mk(SQ_LD_F(SQ_STRENGTH, j), SQ_LD_F(SQ_STRENGTH + 1, j), SQ_LD_F(SQ_STRENGTH + 2, j));
           bounces = SQ_LD_U(SQ_BOUNCES, j), s = SQ_LD_U(SQ_SAMPLE, j);
+          RT_TL_BOUNCES(bounces);
           if (COUNT && tr_out) trd = SQ_LD_U(SQ_TRACE, j), tra = SQ_LD_U(SQ_TRACE + 1, j), trp = SQ_LD_U(SQ_TRACE + 2, j);
           const uint32_t xy = SQ_LD_U(SQ_XY, j);
           x = xy & 0xffffu, row = xy >> 16;
@@ -359,6 +368,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         }
         if (cm.lpt_samples) lpt_count(cm, lpt_on, lpt_on ? pixel_to_work(P, load_const(&lc->pm), x, row) >> 8 : 0u);
         const uint64_t m_live = __builtin_amdgcn_ballot_w64(live), m_end = __builtin_amdgcn_ballot_w64(ended);
+        RT_TL_SHADE(take, m_live);
         if (live) {  // push onto T
           const uint32_t i = t_count + lane_rank(m_live);
           TQ_ST_F(TQ_O, i, so.x), TQ_ST_F(TQ_O + 1, i, so.y), TQ_ST_F(TQ_O + 2, i, so.z);
@@ -423,6 +433,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
             if (base >= total_work) {
               exhausted = true;
               if (COUNT) t_exhausted = RT_TICK();
+              RT_TL_EXHAUSTED(FPOOL - n_dead - n_count - take, t_count + tn_count, s_count, x_count);
             } else {
               w_chunk = lpt_reservation(cm, base, lane, w_delta, w_lpt_ready);
               w_next = base;
@@ -460,7 +471,11 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           float stime;
           get_ray(cam, u, v, rng, so, sd, stime);
           if (COUNT) total_draws += rng.draws;
+#if RT_T_PRIORITY
+          const uint32_t i = FPOOL - 1u - (tn_count + lane_rank(m_live));
+#else
           const uint32_t i = t_count + lane_rank(m_live);
+#endif
           TQ_ST_F(TQ_O, i, so.x), TQ_ST_F(TQ_O + 1, i, so.y), TQ_ST_F(TQ_O + 2, i, so.z);
           TQ_ST_F(TQ_D, i, sd.x), TQ_ST_F(TQ_D + 1, i, sd.y), TQ_ST_F(TQ_D + 2, i, sd.z);
           TQ_ST_F(TQ_TIME, i, stime);
@@ -470,13 +485,22 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           if (COUNT && tr_out) TQ_ST_U(TQ_TRACE, i, rng.draws), TQ_ST_U(TQ_TRACE + 1, i, 0u), TQ_ST_U(TQ_TRACE + 2, i, 0u);
           if (COUNT) cnt.rays++;
         }
+#if RT_T_PRIORITY
+        tn_count += (uint32_t)__builtin_popcountll(m_live);
+#else
         t_count += (uint32_t)__builtin_popcountll(m_live);
+#endif
         n_dead += take - (uint32_t)__builtin_popcountll(m_live);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         if (COUNT) t_gen += RT_TICK() - t_mark2;
+        RT_TL_ALIVE(FPOOL - n_dead - n_count);
       };
-      for (;;) {  // full passes first; partial ones only when the lanes would have nothing to traverse (ONE call site per pass kind)
-        const bool any_part = n_busy == 0 && t_count == 0;
+      // full passes first; partial ones only when the lanes would have nothing to traverse (ONE call site per pass kind) -- and then
+      // for EVERY stack that holds something: when only the first non-empty stack was served, the paths waiting in S and in X took
+      // turns, each population idle while the other traversed (drain of a launch: r04a_tl_book2_*: > 64 live paths, 5 rays per generation)
+      const bool drain_all = RT_DRAIN_ALL && n_busy == 0 && t_count + tn_count == 0;
+      for (;;) {
+        const bool any_part = drain_all || (n_busy == 0 && t_count + tn_count == 0);
         uint32_t which = s_count >= 64u ? 1u : (TEX && x_count >= 64u) ? 2u : n_count >= 64u ? 3u : 0u;
         if (which == 0u && any_part) which = n_count ? 3u : s_count ? 1u : (TEX && x_count) ? 2u : 0u;
         if (which == 0u) break;
@@ -488,11 +512,13 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
       {  // (3) refill from T
         const uint64_t m_idle = __builtin_amdgcn_ballot_w64(!have_ray);
         const uint32_t n_idle = (uint32_t)__builtin_popcountll(m_idle);
-        const uint32_t got = n_idle < t_count ? n_idle : t_count;
+        const uint32_t t_all = t_count + tn_count;
+        const uint32_t got = n_idle < t_all ? n_idle : t_all;
         if (got) {
           const uint32_t r = lane_rank(m_idle);
+          const uint32_t take_c = got < t_count ? got : t_count;  // continuing rays first (rt_pool.h RT_T_PRIORITY)
           if (!have_ray && r < got) {
-            const uint32_t i = t_count - 1u - r;  // pop
+            const uint32_t i = r < take_c ? t_count - 1u - r : FPOOL - tn_count + (r - take_c);  // pop
             o = mk(TQ_LD_F(TQ_O, i), TQ_LD_F(TQ_O + 1, i), TQ_LD_F(TQ_O + 2, i));
             d = mk(TQ_LD_F(TQ_D, i), TQ_LD_F(TQ_D + 1, i), TQ_LD_F(TQ_D + 2, i));
             time = TQ_LD_F(TQ_TIME, i);
@@ -505,8 +531,9 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
             if (COUNT) tr_a0 = cnt.aabb, tr_p0 = cnt.prim;
             have_ray = true;
           }
-          t_count -= got;
+          t_count -= take_c, tn_count -= got - take_c;
           if (COUNT) n_refill++;
+          RT_TL_REFILL(got);
         }
       }
       // 1/d and the current record of EVERY lane are (re)derived here -- the same bits for a lane that kept its ray -- so
@@ -515,6 +542,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
       cur_lo = RT_FETCH_LO(pc), cur_hi = RT_FETCH_HI(pc);
       if (COUNT) t_refill += RT_TICK() - t_mark2;
       if (COUNT) t_serv += RT_TICK() - t_mark;
+      RT_TL_SERVICE();
       if (n_dead == FPOOL) break;
       if (__builtin_amdgcn_ballot_w64(have_ray) == 0) continue;
       op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
@@ -532,6 +560,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
     if (64u - busy >= tune.refill_min || busy == 0) break;
     }
   }
+  RT_TL_DONE();
   if (COUNT) {
     atomicAdd(&counters[0], (unsigned long long)cnt.aabb);
     atomicAdd(&counters[1], (unsigned long long)cnt.prim);

@@ -225,6 +225,10 @@ __device__ __attribute__((noinline)) BoundaryHit boundary_hit_t(const uint4* __r
       n_prim++;
       V3 lo_o = o;
       if (hi.w & F_TRANSLATE) lo_o = vsub(o, mk(u2f(lo.x), u2f(lo.y), u2f(lo.z)));
+      if (hi.w & F_MOVE) {  // fused LinearMove (flat_scene.h): motion in the OP_EXT record behind
+        const uint4 mv = prog_lo[++pc];
+        lo_o = vsub(lo_o, smul(time, mk(u2f(mv.x), u2f(mv.y), u2f(mv.z))));
+      }
       float t;
       if (sphere_hit_t(lo_o, d, u2f(lo.w), t_lo, best, t)) best = t, any = true;
       pc++;
@@ -316,6 +320,10 @@ __device__ __attribute__((noinline)) bool walk_deep(const DevScene& sc, uint32_t
       V3 off = mk(u2f(lo.x), u2f(lo.y), u2f(lo.z));
       V3 lo_o = o;
       if (hi.w & F_TRANSLATE) lo_o = vsub(o, off);
+      if (hi.w & F_MOVE) {  // fused LinearMove (flat_scene.h)
+        const uint4 mv = sc.lo[++pc];
+        lo_o = vsub(lo_o, smul(time, mk(u2f(mv.x), u2f(mv.y), u2f(mv.z))));
+      }
       float t;
       if (sphere_hit_t(lo_o, d, u2f(lo.w), t_lo, best, t)) {
         if (rec) {
@@ -489,6 +497,10 @@ RT_DEV bool hit_top(const DevScene& sc, V3 o, V3 d, float time, float t_near, Sa
       V3 off = mk(u2f(lo.x), u2f(lo.y), u2f(lo.z));
       V3 lo_o = o;
       if (hi.w & F_TRANSLATE) lo_o = vsub(o, off);  // object.rs:275-278
+      if ((FEAT & FEAT_XFORM) && (hi.w & F_MOVE)) {  // fused LinearMove, object.rs:505-508 (flat_scene.h)
+        const uint4 mv = sc.lo[++pc];
+        lo_o = vsub(lo_o, smul(time, mk(u2f(mv.x), u2f(mv.y), u2f(mv.z))));
+      }
       float t;
       if (sphere_hit_t(lo_o, d, u2f(lo.w), t_near, best, t)) {
         V3 p = vadd(lo_o, smul(t, d));              // ray.rs:15

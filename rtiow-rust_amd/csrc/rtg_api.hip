@@ -114,6 +114,19 @@ struct rtg_scene {
   LaunchCtx* cx = &ctx[0];                 // the context of the call being made (ctx_acquire)
 };
 
+// A context that leaves the ring (frames_in_flight lowered) or whose scene is destroyed: wait for its frame, free what it
+// holds (the sample scratch alone may be a large part of the HBM).  The events and the small buffers stay for reuse.
+static void ctx_free_buffers(LaunchCtx* c) {
+  if (c->busy) (void)hipEventSynchronize(c->done);
+  c->busy = false;
+  if (c->d_scratch) (void)hipFree(c->d_scratch);
+  if (c->d_slots) (void)hipFree(c->d_slots);
+  if (c->d_stack) (void)hipFree(c->d_stack);
+  if (c->d_lpt) (void)hipFree(c->d_lpt);
+  c->d_scratch = nullptr, c->scratch_bytes = 0, c->d_slots = nullptr, c->slots_bytes = 0;
+  c->d_stack = nullptr, c->stack_bytes = 0, c->d_lpt = nullptr, c->lpt_bytes = 0;
+}
+
 // Take the next launch context of the ring: create its small buffers on first use, wait for the frame that used it last.
 static int ctx_acquire(rtg_scene* s) {
   LaunchCtx* c = &s->ctx[s->next_ctx];
@@ -406,12 +419,8 @@ void rtg_scene_destroy(rtg_scene* s) {
   for (void* p : s->buffers)
     if (p) (void)hipFree(p);
   for (LaunchCtx& c : s->ctx) {
-    if (c.busy) (void)hipEventSynchronize(c.done);
+    ctx_free_buffers(&c);
     if (c.d_counters) (void)hipFree(c.d_counters);
-    if (c.d_scratch) (void)hipFree(c.d_scratch);
-    if (c.d_slots) (void)hipFree(c.d_slots);
-    if (c.d_stack) (void)hipFree(c.d_stack);
-    if (c.d_lpt) (void)hipFree(c.d_lpt);
     if (c.d_consts) (void)hipFree(c.d_consts);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);
@@ -514,6 +523,8 @@ int rtg_scene_set_option(rtg_scene* s, const char* name, int value) {
   }
   else if (k == "frames_in_flight") {  // launch contexts of this handle: asynchronous rtg_par_cast_device calls overlap up to this many frames
     if (value < 1 || value > RTG_MAX_FRAMES) return fail(RTG_ERR_INVALID, "frames_in_flight: 1 .. 4");
+    HIP_TRY(hipSetDevice(s->device));
+    for (int i = value; i < RTG_MAX_FRAMES; i++) ctx_free_buffers(&s->ctx[i]);  // contexts that leave the ring: wait for their frame, give the HBM back
     s->n_ctx = value, s->next_ctx = 0;
   }
   else if (k == "force_rccl") s->force_rccl = value;
@@ -606,18 +617,54 @@ int rtg_par_cast_device(rtg_scene* s, const rtg_camera* camera, const rtg_params
   if ((rc = ctx_acquire(s))) return rc;
   DevCamera cam = to_dev(camera);
   bool count = stats && (params->flags & RTG_FLAG_COUNTERS);
+  // From here on work of this frame may sit on `stream`: a failure must not hand the context out again while kernels of the
+  // partly enqueued frame still run (they read d_consts / d_lpt / the scratch the next call would rewrite) -- drain first.
+#define HIP_TRY_CTX(expr)                               \
+  do {                                                  \
+    hipError_t e_ = (expr);                             \
+    if (e_ != hipSuccess) {                             \
+      (void)hipStreamSynchronize(stream);               \
+      return hip_fail(e_, #expr);                       \
+    }                                                   \
+  } while (0)
   if (count) {
-    HIP_TRY(hipMemsetAsync(s->cx->d_counters, 0, 7 * sizeof(unsigned long long), stream));
-    HIP_TRY(hipMemsetAsync(s->cx->d_counters + 8, 0, 24 * sizeof(unsigned long long), stream));
+    HIP_TRY_CTX(hipMemsetAsync(s->cx->d_counters, 0, 7 * sizeof(unsigned long long), stream));
+    HIP_TRY_CTX(hipMemsetAsync(s->cx->d_counters + 8, 0, 24 * sizeof(unsigned long long), stream));
   }
-  if (stats) HIP_TRY(hipEventRecord(s->cx->ev0, stream));
-  HIP_TRY(count ? launch_render<true>(s, cam, d, d_out, stream) : launch_render<false>(s, cam, d, d_out, stream));
-  if ((rc = ctx_release(s, stream))) return rc;
+#ifdef RT_TIMELINE  // diagnostic build (rt_pool.h RT_TL_*): one 16-dword drain record per wave, dumped to $RTG_TIMELINE_OUT
+  static uint32_t* d_tl = nullptr;
+  const size_t tl_bytes = (size_t)1024 * 16 * 16 * sizeof(uint32_t);  // <= 1024 workgroups x 16 waves
+  if (!count) {
+    if (!d_tl) HIP_TRY_CTX(hipMalloc((void**)&d_tl, tl_bytes));
+    HIP_TRY_CTX(hipMemsetAsync(d_tl, 0, tl_bytes, stream));
+    static unsigned long long tl_ptr;
+    tl_ptr = (unsigned long long)(uintptr_t)d_tl;
+    HIP_TRY_CTX(hipMemcpyAsync(s->cx->d_counters + 31, &tl_ptr, sizeof(tl_ptr), hipMemcpyHostToDevice, stream));
+  }
+#endif
+  if (stats) HIP_TRY_CTX(hipEventRecord(s->cx->ev0, stream));
+  HIP_TRY_CTX(count ? launch_render<true>(s, cam, d, d_out, stream) : launch_render<false>(s, cam, d, d_out, stream));
+  if ((rc = ctx_release(s, stream))) {
+    (void)hipStreamSynchronize(stream);
+    return rc;
+  }
+#undef HIP_TRY_CTX
   if (stats) {
     HIP_TRY(hipEventRecord(s->cx->ev1, stream));
     HIP_TRY(hipEventSynchronize(s->cx->ev1));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, s->cx->ev0, s->cx->ev1));
+#ifdef RT_TIMELINE
+    if (!count && getenv("RTG_TIMELINE_OUT")) {
+      std::vector<uint32_t> h_tl(tl_bytes / sizeof(uint32_t));
+      HIP_TRY(hipMemcpy(h_tl.data(), d_tl, tl_bytes, hipMemcpyDeviceToHost));
+      if (FILE* f = fopen(getenv("RTG_TIMELINE_OUT"), "wb")) {
+        fwrite(&ms, sizeof(ms), 1, f);
+        fwrite(h_tl.data(), 1, tl_bytes, f);
+        fclose(f);
+      }
+    }
+#endif
     stats->kernel_ms = ms;
     stats->samples = owned_pixels(d) * d.ns;
     unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};

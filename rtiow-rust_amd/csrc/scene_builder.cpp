@@ -247,26 +247,37 @@ static uint32_t mat_flags(const SceneBuilder& b, uint32_t mat) {
   return (m.kind << F_MATKIND_SHIFT) | (textured ? F_TEXTURED : 0u);
 }
 
-// Peel FlipNormals* [Translate] FlipNormals* Sphere, or FlipNormals* Rect, into one fused record.
-// (FlipNormals commutes exactly with Translate: one negates the normal, the other shifts p.)
-static bool fuse_primitive(const SceneBuilder& b, uint32_t id, FlatScene* out, bool emit_it) {
-  bool flip = false, have_t = false;
-  float off[3] = {0, 0, 0};
+// Peel FlipNormals* [Translate] FlipNormals* [LinearMove] FlipNormals* Sphere, or FlipNormals* Rect, into one fused record.
+// (FlipNormals commutes exactly with Translate and LinearMove: one negates the normal, the others shift the origin / p.
+// The LinearMove must sit INSIDE the Translate -- the order of the two subtractions is the reference's, object.rs:275-278 then
+// 505-508 -- and is only peeled where the caller can execute it: `allow_move`.)
+static bool fuse_primitive(const SceneBuilder& b, uint32_t id, FlatScene* out, bool emit_it, bool allow_move) {
+  bool flip = false, have_t = false, have_m = false;
+  float off[3] = {0, 0, 0}, motion[3] = {0, 0, 0};
   for (;;) {
     const HostObject& o = b.objects[id];
     if (o.kind == HostObject::FLIP) {
       flip = !flip;
       id = o.a;
-    } else if (o.kind == HostObject::TRANSLATE && !have_t) {
+    } else if (o.kind == HostObject::TRANSLATE && !have_t && !have_m) {
       have_t = true;
       off[0] = o.f[0], off[1] = o.f[1], off[2] = o.f[2];
       id = o.a;
+    } else if (o.kind == HostObject::MOVE && !have_m && allow_move) {
+      have_m = true;
+      motion[0] = o.f[0], motion[1] = o.f[1], motion[2] = o.f[2];
+      id = o.a;
     } else if (o.kind == HostObject::SPHERE) {
-      if (emit_it)
+      if (emit_it) {
         push(out, off[0], off[1], off[2], o.f[0], 0, 0, o.mat,
-             OP_SPHERE | (have_t ? F_TRANSLATE : 0u) | (flip ? F_FLIP : 0u) | mat_flags(b, o.mat));
+             OP_SPHERE | (have_t ? F_TRANSLATE : 0u) | (have_m ? F_MOVE : 0u) | (flip ? F_FLIP : 0u) | mat_flags(b, o.mat));
+        if (have_m) {
+          push(out, motion[0], motion[1], motion[2], 0, 0, 0, 0, OP_EXT);
+          out->features |= FEAT_XFORM;  // the ray's time matters: not a lean program
+        }
+      }
       return true;
-    } else if (o.kind == HostObject::RECT && !have_t) {
+    } else if (o.kind == HostObject::RECT && !have_t && !have_m) {
       if (emit_it) {
         push(out, o.f[0], o.f[1], o.f[2], o.f[3], fbits(o.f[4]), 0, o.mat,
              OP_RECT | ((uint32_t)o.axis << F_AXIS_SHIFT) | (flip ? F_FLIP : 0u) | mat_flags(b, o.mat));
@@ -349,7 +360,7 @@ void SceneBuilder::emit_bvh(int32_t node_id, int depth, FlatScene* out, int boun
 
 void SceneBuilder::emit(uint32_t id, bool under_bvh, int depth, FlatScene* out, int boundary, bool mark_roots, int saves) const {
   const HostObject& o = objects[id];
-  if (fuse_primitive(*this, id, out, true)) return;
+  if (fuse_primitive(*this, id, out, true, true)) return;
   switch (o.kind) {
     case HostObject::AND: {
       float p0[3], p1[3];
@@ -394,13 +405,13 @@ void SceneBuilder::emit(uint32_t id, bool under_bvh, int depth, FlatScene* out, 
       }
       {
         const size_t at = out->lo.size();
-        const bool single = fuse_primitive(*this, o.a, out, false);
+        const bool single = fuse_primitive(*this, o.a, out, false, false);  // (a moving boundary is an object graph: boundary_pair_t knows no time)
         push(out, o.f[0], 0, 0, 0, 0, 0, o.mat,
              OP_MEDIUM | (under_bvh ? F_UNDER_BVH : 0u) | (single ? 0u : F_GENERAL_BOUNDARY) | mat_flags(*this, o.mat));
         // the boundary's own stream: evaluated twice per medium test by a nested walk (object.rs:551-552),
         // skipped by the main walk.  It starts a fresh wrapper depth (its rays are saved on a private stack).
         if (single) {
-          fuse_primitive(*this, o.a, out, true);
+          fuse_primitive(*this, o.a, out, true, false);
         } else {
           emit(o.a, false, 0, out, boundary + 1, holds_medium(o.a), 0), out->features |= FEAT_BOUNDARY;
           push(out, 0, 0, 0, 0, 0, 0, (uint32_t)at, OP_BEND);  // where a range-query walk of the stream finishes

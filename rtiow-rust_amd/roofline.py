@@ -7,11 +7,14 @@ every `issue_cycles` = 2 shader cycles (MI355X_MICROARCH.md "Wave scheduling"; t
 s_memtime inside the kernel, reaches 2.17 cycles per instruction on the box step's own instruction mix from 2 waves
 per SIMD on, 2.7 on a single repeated add / mul / fma, ~4.5 on max3 / cmp / v_pk_* / integer multiplies).  Hence
 
-    peak      = CUs x 4 SIMDs x 2.4 GHz (max clock) / issue_cycles   [wave-instructions / s]
-    achieved  = SQ_INSTS_VALU per launch / kernel seconds             [wave-instructions / s]
-    frac      = achieved / peak                      -- how busy the VALU issue ports are
     lane_util = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)    -- how many of the 64 lanes do work
-    frac x lane_util = fraction of the f32 lane peak doing useful work (divergence included)
+    peak      = CUs x 4 SIMDs x 64 lanes x 2.4 GHz (max clock) / issue_cycles        [lane-instructions / s]
+    achieved  = SQ_INSTS_VALU per launch x 64 x lane_util / kernel seconds           [lane-instructions / s]
+    frac      = achieved / peak       -- the fraction of the f32 lane peak doing work (divergence included): THE figure of merit
+    valu_issue.frac = SQ_INSTS_VALU / kernel seconds / (CUs x 4 SIMDs x clock / issue_cycles) -- how busy the issue ports are
+                      (a secondary: removing instructions lowers it while the kernel gets faster)
+    extrapolated = the timed launch renders another number of samples than the profiled one: the counters are scaled per
+                   sample, i.e. the fixed part of a launch is mis-weighted -- collect counters at the named config instead
 
 and next to it the measured HBM side (rocprofv3 FETCH_SIZE / WRITE_SIZE, corrected as the guide prescribes) against
 the 8 TB/s peak, and the LDS array duty (SQ_LDS_IDX_ACTIVE / CU-cycles).  The SURVEY 8(d) "algorithmic bytes" figure
@@ -80,8 +83,8 @@ def valu_roofline(pmc, kernel_s, samples=None, clock_hz=None, issue_cycles=None,
     stale: profile_staleness()'s verdict -- counters of another build give achieved / frac = null and the reason."""
     if stale:
         clock = clock_hz or NOMINAL_CLOCK_HZ
-        return {"bound": "valu", "achieved": None, "peak": N_CUS * SIMDS_PER_CU * clock / (issue_cycles or ISSUE_CYCLES) / 1e9,
-                "unit": "G wave-instructions/s", "frac": None, "traffic": None, "stale_profile": stale}
+        return {"bound": "valu", "achieved": None, "peak": N_CUS * SIMDS_PER_CU * 64 * clock / (issue_cycles or ISSUE_CYCLES) / 1e9,
+                "unit": "G lane-instructions/s", "frac": None, "traffic": None, "stale_profile": stale}
     c = pmc["counters_avg_per_launch"]
     scale = 1.0
     if samples is not None and pmc.get("samples_per_launch"):
@@ -89,16 +92,20 @@ def valu_roofline(pmc, kernel_s, samples=None, clock_hz=None, issue_cycles=None,
     insts = c["SQ_INSTS_VALU"] * scale
     clock = clock_hz or NOMINAL_CLOCK_HZ   # the chip's maximum clock: the profiled launch itself ran at pmc["shader_clock_hz"]
     cyc = issue_cycles or pmc.get("issue_cycles") or ISSUE_CYCLES
-    peak = N_CUS * SIMDS_PER_CU * clock / cyc
-    achieved = insts / kernel_s
+    issue_peak = N_CUS * SIMDS_PER_CU * clock / cyc
+    issued = insts / kernel_s
     lane_util = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]) if c.get("SQ_ACTIVE_INST_VALU") else None
     out = {
         "bound": "valu",
-        "achieved": achieved / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s",
-        "frac": achieved / peak,
+        # THE fraction: lanes doing work / the f32 lane peak (issue fraction x lane utilisation)
+        "achieved": issued * 64 * lane_util / 1e9 if lane_util else None, "peak": issue_peak * 64 / 1e9, "unit": "G lane-instructions/s",
+        "frac": (issued / issue_peak) * lane_util if lane_util else None,
+        "frac_definition": "active f32 lanes of issued VALU instructions / (256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / 2 cycles per wave64 instruction)",
+        "valu_issue": {"achieved": issued / 1e9, "peak": issue_peak / 1e9, "unit": "G wave-instructions/s", "frac": issued / issue_peak},
         "valu_wave_instructions_per_launch": insts,
         "lane_utilization": lane_util,
-        "frac_of_f32_lane_peak": (achieved / peak) * lane_util if lane_util else None,
+        "extrapolated": bool(abs(scale - 1.0) > 1e-9),
+        "profiled_samples_per_launch": pmc.get("samples_per_launch"),
         "shader_clock_hz": clock, "shader_clock_measured_hz": pmc.get("shader_clock_hz"),
         "issue_cycles_per_wave_instruction": cyc,
     }
@@ -116,17 +123,28 @@ def valu_roofline(pmc, kernel_s, samples=None, clock_hz=None, issue_cycles=None,
     return out
 
 
-def find_profile(root, workload_key):
-    """profiles/current.json maps a workload key ("book1", "book2", "cornell") to the pmc_summary.json of the kernel
-    build that is checked in (written by tools/collect_profiles.sh)."""
+def find_profile(root, workload_key, spp=None):
+    """profiles/current.json maps a workload key ("book1", "book2", "cornell", and "<workload>@<spp>" for counters collected
+    at another named config: "book1@500" = C3's frame, "book2@1000" = C4) to the pmc_summary.json of the kernel build that is
+    checked in (written by tools/collect_profiles.sh).  The entry of the timed launch's own spp wins; the workload's base
+    entry is the fallback, and valu_roofline then marks the object `extrapolated`."""
     idx = os.path.join(root, "profiles", "current.json")
     if not os.path.exists(idx):
         return None, None
     try:
-        rel = json.load(open(idx)).get(workload_key)
+        cur = json.load(open(idx))
+        rel = (cur.get("%s@%d" % (workload_key, spp)) if spp else None) or cur.get(workload_key)
         if not rel:
             return None, None
         path = os.path.join(root, rel)
         return load_pmc(path), rel
     except Exception:
         return None, None
+
+
+def knob_differences(pmc, environ):
+    """RTG_* schedule options that differ between the profiled run (pmc["env_options"]) and the current environment, in
+    EITHER direction: set now but not then, set then but not now, or set to another value."""
+    then = {k: v for k, v in pmc.get("env_options", {}).items() if k.startswith("RTG_") and k != "RTG_BENCH_BACKEND"}
+    now = {k: v for k, v in environ.items() if k.startswith("RTG_") and k != "RTG_BENCH_BACKEND"}
+    return sorted(k for k in set(then) | set(now) if then.get(k) != now.get(k))

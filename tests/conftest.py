@@ -54,3 +54,12 @@ def assert_bit_equal(a, b, what=""):
         first = tuple(idx[0])
         raise AssertionError("%s: %d of %d floats differ; first at %s: %r vs %r" % (
             what, idx.shape[0], a.size, first, a[first], b[first]))
+
+
+def free_port():
+    """A rendezvous port nobody holds right now (bind port 0, as bench.py self_launch does): two suites on one host
+    must not meet on a fixed number."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

@@ -134,7 +134,19 @@ def test_flat_program_of_cornell_and_book2(pkg):
     ops = words[:, 7] & 0xff
     assert feat == 15 | 64                             # every geometry / texture feature + "an albedo (Perlin) may exceed 1"
     assert int((ops == OP_MEDIUM).sum()) == 2 and int((ops == OP_RECT).sum()) == 1 and int((ops == OP_PRISM).sum()) == 400
-    assert int((ops == OP_PUSH).sum()) == 2               # Translate{LinearMove{Sphere}}, Translate{RotateY{Bvh}}: one level each
+    assert int((ops == OP_PUSH).sum()) == 1               # Translate{RotateY{Bvh}}: one wrapper level
+    # Translate{LinearMove{Sphere}} (main.rs:218-229) is ONE fused SPHERE record (F_TRANSLATE | F_MOVE) + its motion vector
+    mv = np.nonzero((ops == OP_SPHERE) & ((words[:, 7] >> 20) & 1 == 1))[0]
+    assert len(mv) == 1 and ops[mv[0] + 1] == 11 and words[mv[0], 7] & (1 << 8)
+    assert words[mv[0], :4].view(np.float32).tolist() == [400.0, 400.0, 200.0, 50.0]
+    assert words[mv[0] + 1, :3].view(np.float32).tolist() == [30.0, 0.0, 0.0]
+    # ... only in the order the reference applies them: LinearMove{Translate{Sphere}} keeps its wrapper (around a fused Translate)
+    b2 = be.builder()
+    m = b2.lambertian(b2.constant(pkg.scenes.vfrom(0.5)))
+    w2, _ = b2.flatten([b2.linear_move(b2.translate(pkg.scenes.v(1, 2, 3), b2.sphere(1.0, m)), pkg.scenes.v(1, 0, 0))])
+    assert (w2[:, 7] & 0xff).tolist() == [OP_PUSH, OP_SPHERE, OP_POP, OP_END] and not (w2[1, 7] >> 20) & 1
+    w3, _ = b2.flatten([b2.flip_normals(b2.linear_move(b2.sphere(1.0, m), pkg.scenes.v(0, 1, 0)))])
+    assert (w3[:, 7] & 0xff).tolist() == [OP_SPHERE, 11, OP_END] and (w3[0, 7] >> 20) & 1 and (w3[0, 7] >> 9) & 1 and not w3[0, 7] & (1 << 8)
     assert int((ops == OP_BOX).sum()) == (2 * 400 - 1) + (2 * 1000 - 1)
     med = np.nonzero(ops == OP_MEDIUM)[0]
     assert (ops[med + 1] == OP_SPHERE).all()            # boundary record follows its medium

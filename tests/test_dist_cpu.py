@@ -36,7 +36,8 @@ def test_two_rank_gloo_reduce_equals_single_frame(tmp_path, pkg, oracle):
     out = str(tmp_path / "frame.npy")
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", WORLD_SIZE="2")
+    from conftest import free_port
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script), out], env=dict(env, RANK=str(r))) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=300) == 0

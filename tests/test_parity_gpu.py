@@ -500,10 +500,11 @@ def test_bench_multi_rank_path_on_one_gpu(tmp_path, scaling):
     import json
     import subprocess
     import sys
+    from conftest import free_port
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RTG_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29541" if scaling == "strong" else "29543", os.path.join(root, "bench.py"),
+           "127.0.0.1", "--master-port", str(free_port()), os.path.join(root, "bench.py"),
            "--gpus", "2", "--steps", "2", "--warmup", "1", "--nx", "320", "--ny", "192", "--verify", "--no-cpu-baseline",
            "--scaling", scaling]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)

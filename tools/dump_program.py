@@ -12,7 +12,7 @@ fn, nx, ny, ns = scene_cases.CASES[name]
 b = be.builder()
 world, cam, _ = fn(pkg, b, nx, ny)
 words, feat = b.flatten(world)
-OPS = ["END", "BOX", "SPHERE", "RECT", "PUSH", "POP", "MEDIUM", "PRISM", "BEND"]
+OPS = ["END", "BOX", "SPHERE", "RECT", "PUSH", "POP", "MEDIUM", "PRISM", "BEND", "SAVE", "MERGE", "EXT"]
 ops = words[:, 7] & 0xff
 print("%s: %d records, features 0x%x" % (name, len(words), feat), dict(collections.Counter(OPS[o] for o in ops)))
 pc, depth = 0, 0
