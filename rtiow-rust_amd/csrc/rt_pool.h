@@ -183,6 +183,12 @@ struct ChunkMode {
   // colours exceed the scratch budget (rtg_launch.inc samples_per_pass); the fold kernel carries the running per-pixel sum
   // from pass to pass in the framebuffer itself, so the fold stays the reference's left fold (lib.rs:365-374).
   uint32_t s_begin;
+  // Work items a wave reserves per global atomic: WORK_BLOCK (256) for frames that fill the chip several times over (and always
+  // with the cost-ordered queue, whose blocks are 256 pixels); 64 = one item per lane for small frames, where a 256-item
+  // reservation would leave most waves without work and make the others run four generations one after another
+  // (rtg_launch.inc pool_geometry).  pix_work is a multiple of 256, so a reservation never straddles a chunk.
+  uint32_t work_block;
+  uint32_t donate_max;  // full-feature pool kernel: drain-phase work sharing (rt_pool_full.h RT_DRAIN_SHARE), 0 = off
 };
 RT_DEV uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -298,7 +304,8 @@ RT_DEV T load_const(const T* p) {
   for (uint32_t i = 0; i < sizeof(T) / 4u; i++) dst[i] = w[i];
   return c;
 }
-__global__ void write_launch_consts(LaunchConsts* dst, LaunchConsts v) { *dst = v; }
+// (also resets the work-queue head of the launch: one stream operation less per sample pass than a hipMemsetAsync)
+__global__ void write_launch_consts(LaunchConsts* dst, LaunchConsts v, unsigned long long* queue) { *dst = v, *queue = 0ull; }
 
 // stream-ordered update of the descriptor (a kernel argument by value: no host buffer has to outlive the call)
 __global__ void write_lpt_descriptor(LptQueue* dst, LptQueue v) { *dst = v; }
@@ -383,6 +390,23 @@ inline size_t pool_lds_bytes(uint32_t image_bytes, uint32_t n_mat, uint32_t wave
   b = (b + 15) & ~(size_t)15;
   if (hot_lds) b += (size_t)waves * POOL * (6 * sizeof(float) + sizeof(float) + (stage_program ? 2 : 4));
   return (b + 15) & ~(size_t)15;
+}
+
+// spin lock + relaxed load on LDS control words of a workgroup (rt_pool_full.h: drain-phase work sharing)
+RT_DEV uint32_t pool_lds_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+RT_DEV void pool_lock(uint32_t* lock_word, uint32_t lane) {
+  if (lane == 0u) {
+    for (;;) {
+      uint32_t expect = 0u;
+      if (__hip_atomic_compare_exchange_strong(lock_word, &expect, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+RT_DEV void pool_unlock(uint32_t* lock_word, uint32_t lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (waits for the record loads and stores of every lane)
+  if (lane == 0u) __hip_atomic_store(lock_word, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -894,7 +918,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           if (need == 0) break;
           if (w_next == w_end && !exhausted) {
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(queue, WORK_BLOCK);
+            if (lane == 0) base = atomicAdd(queue, cm.work_block);
             base = __builtin_amdgcn_readfirstlane(base);
             if (base >= total_work) {
               exhausted = true;
@@ -903,7 +927,7 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
             } else {
               if (cm.scratch) w_chunk = lpt_reservation(cm, base, lane, w_delta, w_lpt_ready);
               w_next = base;
-              w_end = (total_work - base < WORK_BLOCK) ? total_work : base + WORK_BLOCK;
+              w_end = (total_work - base < cm.work_block) ? total_work : base + cm.work_block;
             }
           }
           const uint32_t avail = w_end - w_next;

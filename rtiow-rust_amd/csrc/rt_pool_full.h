@@ -50,9 +50,34 @@ enum FullSField : uint32_t {  // S / X stacks: a finished ray with its hit recor
 enum FullNField : uint32_t { NQ_SAMPLE = 0, NQ_XY = 1, NQ_FIELDS = 2 };  // N stack: a path that ended asks for its successor
 constexpr uint32_t NQ_NEED_ITEM = 0xffffffffu;  // NQ_SAMPLE: "the next work item" instead of "sample s of the same pixel"
 constexpr uint32_t FPOOL_FIELDS = TQ_FIELDS + 2 * SQ_FIELDS + NQ_FIELDS;  // dwords of stack space per path in flight (T, S, X, N)
+// stack space of a workgroup: its waves' stacks, then its hand-over stack (RT_DRAIN_SHARE: [field][position] rows of T records)
+inline size_t full_pool_wg_words(uint32_t waves) { return (size_t)waves * FPOOL * FPOOL_FIELDS + (size_t)TQ_FIELDS * 256u; }
 
-// LDS = the first `window` program records (all of them when the program fits, 0 = none)
-inline size_t full_pool_lds_bytes(uint32_t window, uint32_t /*waves*/) { return (size_t)window * 32; }
+// Drain-phase work sharing (RT_DRAIN_SHARE).  A launch ends with a DRAIN: the work queue is empty and every wave finishes the paths
+// it holds.  What is left are long bounce chains (book-2: 2.3 % of the samples run into the bounce cap, 51 DEPENDENT generations of
+// traverse + shade), spread unevenly: the waves of a book-2 launch drain for 0.6 .. 4.7 ms (median 2.2), and a generation takes a wave
+// the longer the more rays it holds (~35 us for one ray, ~55 us for twelve: every ray adds record visits of its own).  So a wave
+// that has run dry does not leave: it registers as HUNGRY, and a wave that still holds rays hands half of its T stack -- whole
+// records, a path has no other state -- to a per-workgroup stack in global memory (DQ_CAP records behind an LDS spin lock; the
+// waves of a workgroup share a CU, hence an L1) whenever a hungry wave waits; hungry waves adopt from it.  The chains of a CU end
+// up one or two per wave and finish together; the workgroup leaves when all its waves are hungry and the stack is empty.  A
+// path's RNG streams are keyed by (pixel, sample, event): which wave runs it changes no bit.  Measured (r04g_share_*): book-2
+// 800x800x100 40.7 -> 40.0 ms, the reference's own 300x300x100 frame 11.9 -> 10.7, fixed cost per launch 8.1 -> 6.0 ms, every
+// wave of a launch done within 0.7 ms of the mean (before: 2.3).  What is left of the drain is ONE chain: a path that starts when
+// the queue runs dry and bounces 50 times, ~70 us a generation.
+// The lean kernel (rt_pool.h) does NOT share: built there too (slot ids made workgroup-wide, a 64-entry mailbox of ids in LDS:
+// profiles/r04_experiments/r04i_lean_work_sharing.patch) it gained nothing on book-1 at 50 or 500 spp -- the waves that end a
+// book-1 launch hold ONE chain each -- 5 % at 10 spp, and the code cost the steady state 1.7 % (r04i_lean_share_ab*.txt).
+// (First built the other way round -- the first wave of every SIMD to see the queue empty COLLECTS the rays of the other twelve,
+// because a launch with 4 waves per CU has half the fixed cost -- and measured: no gain, the collectors' generations grow with the
+// rays they hold; profiles/r04_experiments/r04f_consolidate_*.)
+#ifndef RT_DRAIN_SHARE
+#define RT_DRAIN_SHARE 1
+#endif
+constexpr uint32_t DQ_CAP = 256;                                   // records of a workgroup's hand-over stack
+enum DrainCtl : uint32_t { DC_LOCK = 0, DC_COUNT = 1, DC_HUNGRY = 2, DC_WORDS = 16 };
+// LDS = the first `window` program records (all of them when the program fits, 0 = none) + the hand-over control words
+inline size_t full_pool_lds_bytes(uint32_t window, uint32_t /*waves*/) { return (size_t)window * 32 + DC_WORDS * 4; }
 
 // draw `idx` (0-based) of the stream (seed, pixel, sample, event): word idx%4 of Philox block idx/4
 __device__ __attribute__((always_inline)) float event_draw_f32_inline(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t event, uint32_t idx) {
@@ -166,9 +191,14 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   const char* s_bytes = reinterpret_cast<const char*>(s_mem);
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, n_waves = blockDim.x >> 6;
   const size_t gwave = (size_t)blockIdx.x * n_waves + wave;
+  static_assert(DQ_CAP == 256u, "full_pool_wg_words");
+  const size_t wg_words = (size_t)n_waves * (FPOOL * FPOOL_FIELDS) + (size_t)TQ_FIELDS * DQ_CAP;
   // (wave-uniform, but derived from threadIdx: without the readfirstlane the compiler keeps these in VGPRs and loops over the
   // "different" resources of a wave at every access)
-  uint32_t* tq = uniform_ptr(g_slots + gwave * (FPOOL * FPOOL_FIELDS));
+  uint32_t* tq = uniform_ptr(g_slots + (size_t)blockIdx.x * wg_words + (size_t)wave * (FPOOL * FPOOL_FIELDS));
+  uint32_t* ctl = reinterpret_cast<uint32_t*>(s_mem + 2u * (USE_LDS ? window : 0u));  // hand-over control words behind the program
+  if (threadIdx.x < DC_WORDS) ctl[threadIdx.x] = 0u;
+  bool hungry = false;  // this wave has run dry and is counted in ctl[DC_HUNGRY] (wave-uniform)
   const QueueRsrc qr = make_queue_rsrc(tq);                  // rows: T, then S (+X), then G (+R) -- see Q_ROW
   float* stack = uniform_ptr(g_stack + gwave * (STACK_LEVELS * 6 * 64));  // [level][component][lane]; level 0 rides in registers
   for (uint32_t j = lane; j < FPOOL; j += 64u) NQ_ST_U(NQ_SAMPLE, j, NQ_NEED_ITEM);  // FPOOL paths-to-be ask for a work item
@@ -428,7 +458,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           if (need == 0) break;
           if (w_next == w_end && !exhausted) {
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(queue, WORK_BLOCK);
+            if (lane == 0) base = atomicAdd(queue, cm.work_block);
             base = __builtin_amdgcn_readfirstlane(base);
             if (base >= total_work) {
               exhausted = true;
@@ -437,7 +467,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
             } else {
               w_chunk = lpt_reservation(cm, base, lane, w_delta, w_lpt_ready);
               w_next = base;
-              w_end = (total_work - base < WORK_BLOCK) ? total_work : base + WORK_BLOCK;
+              w_end = (total_work - base < cm.work_block) ? total_work : base + cm.work_block;
             }
           }
           const uint32_t avail = w_end - w_next;
@@ -509,6 +539,46 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         else if (TEX) shade_pass(std::true_type{}, XQ, x_count);
       }
       if (COUNT) t_mark2 = RT_TICK();
+#if RT_DRAIN_SHARE
+      if (exhausted && load_const(&lc->cm.donate_max) != 0u) {  // ---- drain-phase work sharing (see DrainCtl) ----
+        const uint32_t copy_rows = (COUNT && tr_out) ? (uint32_t)TQ_FIELDS : (uint32_t)TQ_TRACE;
+        uint32_t* dq = uniform_ptr(g_slots + (size_t)blockIdx.x * wg_words + (size_t)n_waves * (FPOOL * FPOOL_FIELDS));
+        if (n_dead == FPOOL) {  // run dry: register as hungry, adopt what waits on the workgroup's stack
+          if (!hungry || __builtin_amdgcn_readfirstlane(pool_lds_ld(ctl + DC_COUNT)) != 0u) {
+            pool_lock(ctl + DC_LOCK, lane);
+            const uint32_t n = __builtin_amdgcn_readfirstlane(pool_lds_ld(ctl + DC_COUNT));
+            const uint32_t h = __builtin_amdgcn_readfirstlane(pool_lds_ld(ctl + DC_HUNGRY)) + (hungry ? 0u : 1u);  // hungry waves, this one included
+            uint32_t k = (n + h - 1u) / h;  // an even share of what waits
+            k = k < 64u ? k : 64u;
+            if (lane < k) {
+              const uint32_t src = n - k + lane;
+              for (uint32_t f = 0; f < copy_rows; f++) Q_ST(Q_ROW(0u, f), lane, dq[f * DQ_CAP + src]);
+            }
+            if (lane == 0u) {
+              __hip_atomic_store(ctl + DC_COUNT, n - k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __hip_atomic_store(ctl + DC_HUNGRY, k ? h - 1u : h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            pool_unlock(ctl + DC_LOCK, lane);
+            hungry = k == 0u;
+            t_count = k, n_dead -= k;
+          }
+        } else if (w_next == w_end && tn_count == 0u && t_count >= 2u && __builtin_amdgcn_readfirstlane(pool_lds_ld(ctl + DC_HUNGRY)) != 0u) {
+          pool_lock(ctl + DC_LOCK, lane);  // holds rays while a wave of the workgroup has none: hand half of them over
+          const uint32_t n = __builtin_amdgcn_readfirstlane(pool_lds_ld(ctl + DC_COUNT));
+          uint32_t k = t_count / 2u;
+          k = k < 64u ? k : 64u;
+          k = k < DQ_CAP - n ? k : DQ_CAP - n;
+          if (lane < k) {
+            const uint32_t src = t_count - k + lane, dst = n + lane;
+            for (uint32_t f = 0; f < copy_rows; f++) dq[f * DQ_CAP + dst] = Q_LD(Q_ROW(0u, f), src);
+          }
+          if (lane == 0u) __hip_atomic_store(ctl + DC_COUNT, n + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          pool_unlock(ctl + DC_LOCK, lane);
+          t_count -= k, n_dead += k;
+          RT_TL_ALIVE(FPOOL - n_dead - n_count);
+        }
+      }
+#endif
       {  // (3) refill from T
         const uint64_t m_idle = __builtin_amdgcn_ballot_w64(!have_ray);
         const uint32_t n_idle = (uint32_t)__builtin_popcountll(m_idle);
@@ -543,7 +613,17 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
       if (COUNT) t_refill += RT_TICK() - t_mark2;
       if (COUNT) t_serv += RT_TICK() - t_mark;
       RT_TL_SERVICE();
-      if (n_dead == FPOOL) break;
+      if (n_dead == FPOOL) {
+#if RT_DRAIN_SHARE
+        if (load_const(&lc->cm.donate_max) != 0u) {  // leave when every wave of the workgroup has run dry and nothing waits to be adopted
+          if (hungry && __builtin_amdgcn_readfirstlane(pool_lds_ld(ctl + DC_HUNGRY)) == n_waves &&
+              __builtin_amdgcn_readfirstlane(pool_lds_ld(ctl + DC_COUNT)) == 0u) break;
+          __builtin_amdgcn_s_sleep(127);  // (poll every ~3.5 us)
+          continue;
+        }
+#endif
+        break;
+      }
       if (__builtin_amdgcn_ballot_w64(have_ray) == 0) continue;
       op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
     }

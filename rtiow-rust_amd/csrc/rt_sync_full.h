@@ -181,14 +181,14 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         if (need == 0) break;
         if (w_next == w_end && !exhausted) {
           uint32_t base = 0;
-          if (lane == 0) base = atomicAdd(queue, WORK_BLOCK);
+          if (lane == 0) base = atomicAdd(queue, cm.work_block);
           base = __builtin_amdgcn_readfirstlane(base);
           if (base >= total_work) {
             exhausted = true;
           } else {
             w_chunk = lpt_reservation(cm, base, lane, w_delta, w_lpt_ready);
             w_next = base;
-            w_end = (total_work - base < WORK_BLOCK) ? total_work : base + WORK_BLOCK;
+            w_end = (total_work - base < cm.work_block) ? total_work : base + cm.work_block;
           }
         }
         const uint32_t avail = w_end - w_next;

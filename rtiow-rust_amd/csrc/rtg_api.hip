@@ -108,7 +108,11 @@ struct rtg_scene {
   PoolTuning sync_tune{20, 16, 32, 16, 16, 40};  // lock-step kernel (only run_ahead / run_ahead_min / gather_min matter there)
   int wg_per_cu = 0;                       // 0 = ask the occupancy API
   int full_threads = 0;                    // full-feature pool kernel: 0 = the variant's maximum (RTG_BLOCK overrides)
-  int pool_threads = 1024;                 // lean ray-pool kernel: ONE 16-wave workgroup per CU shares one LDS copy of the program
+  int pool_threads = 0;                    // lean ray-pool kernel: 0 = ONE 16-wave workgroup per CU shares one LDS copy of the program (RTG_BLOCK overrides)
+  int donate_max = 1;                      // pool kernels, drain-phase work sharing (rt_pool_full.h RT_DRAIN_SHARE): 0 = off
+  int small_frames = 1;                    // rtg_launch.inc pool_geometry: frames smaller than the chip get small workgroups and reservations
+  struct KernelSetup { const void* kernel; int bt; size_t lds; int per_cu; };
+  std::vector<KernelSetup> kernel_setups;  // (kernel, block, LDS) triples whose attributes are set (rtg_launch.inc kernel_setup)
   LaunchCtx ctx[RTG_MAX_FRAMES];           // frames in flight
   int n_ctx = 1, next_ctx = 0;
   LaunchCtx* cx = &ctx[0];                 // the context of the call being made (ctx_acquire)
@@ -517,7 +521,7 @@ int rtg_scene_set_option(rtg_scene* s, const char* name, int value) {
   else if (k == "ray_lds") s->ray_lds = value;
   else if (k == "bvh4") {
     if (value && !s->wide_bytes) return fail(RTG_ERR_INVALID, "bvh4: the scene is not one Bvh of spheres (no 4-wide image)");
-    if (value && pool_lds_bytes(s->wide_bytes, s->n_mat, (uint32_t)s->pool_threads / 64u, true, false) > 160 * 1024)
+    if (value && pool_lds_bytes(s->wide_bytes, s->n_mat, (uint32_t)(s->pool_threads > 0 ? s->pool_threads : RT_POOL_MAX_THREADS) / 64u, true, false) > 160 * 1024)
       return fail(RTG_ERR_INVALID, "bvh4: the 4-wide image does not fit a CU's 160 KB of LDS (the 4-wide walk only exists LDS-staged)");
     s->bvh4 = value;
   }
@@ -534,6 +538,8 @@ int rtg_scene_set_option(rtg_scene* s, const char* name, int value) {
     s->pool_threads = s->full_threads = value;
   }
   else if (k == "wg_per_cu") s->wg_per_cu = value;
+  else if (k == "donate_max") s->donate_max = value;
+  else if (k == "small_frames") s->small_frames = value;        // 0: one geometry for every frame size (measurement switch)
   else if (k == "verbose") s->verbose = value;                  // print launch geometry / schedule statistics to stderr
   else if (k == "window") s->window = value;                    // full-feature kernel: records staged in LDS, -1 = automatic
   else if (k == "box_leave") s->pool_tune.box_leave = s->full_tune.box_leave = s->sync_tune.box_leave = u;
