@@ -284,14 +284,15 @@ def main():
         kernel_name = {"book1": "rtg::render_lean_pool", "book2": "rtg::render_full_pool", "cornell": "rtg::render_full_sync"}[args.workload]
         kernel_s = avg_kernel_ms * 1e-3
         rank_samples = px_rank * spp
-        pmc, pmc_path = rl.find_profile(ROOT, (args.workload if args.bvh == "reference" else args.workload + "_" + args.bvh) + ("_bvh4" if args.bvh4 else ""), spp)
+        pmc, pmc_path = rl.find_profile(ROOT, (args.workload if args.bvh == "reference" else args.workload + "_" + args.bvh) + ("_bvh4" if args.bvh4 else ""), spp, frame=(nx, ny))
         if pmc is not None:
             # counters are only quoted for the build and schedule they were collected on (profiles carry the git blob hashes
             # of csrc/*): another build, or an RTG_* option set on one side only -> achieved / frac = null + the reason
             knobs = rl.knob_differences(pmc, os.environ)
             stale = rl.profile_staleness(pmc, ROOT, lib_override=os.environ.get("RTIOW_GPU_LIB"), knobs=knobs)
-            if stale is None and (nx, ny) != (wnx, wny):
-                stale = "frame geometry %dx%d differs from the profiled %dx%d" % (nx, ny, wnx, wny)
+            pf = pmc.get("frame") or {"nx": wnx, "ny": wny}
+            if stale is None and (nx, ny) != (pf["nx"], pf["ny"]):
+                stale = "frame geometry %dx%d differs from the profiled %dx%d" % (nx, ny, pf["nx"], pf["ny"])
             roof = rl.valu_roofline(pmc, kernel_s, samples=rank_samples, stale=stale)
             roof["pmc_source"] = pmc_path
             roof["pmc_build"] = pmc.get("build", {}).get("digest")

@@ -123,17 +123,21 @@ def valu_roofline(pmc, kernel_s, samples=None, clock_hz=None, issue_cycles=None,
     return out
 
 
-def find_profile(root, workload_key, spp=None):
-    """profiles/current.json maps a workload key ("book1", "book2", "cornell", and "<workload>@<spp>" for counters collected
-    at another named config: "book1@500" = C3's frame, "book2@1000" = C4) to the pmc_summary.json of the kernel build that is
-    checked in (written by tools/collect_profiles.sh).  The entry of the timed launch's own spp wins; the workload's base
-    entry is the fallback, and valu_roofline then marks the object `extrapolated`."""
+def find_profile(root, workload_key, spp=None, frame=None):
+    """profiles/current.json maps a workload key ("book1", "book2", "cornell", "<workload>@<spp>" for counters collected
+    at another named config: "book1@500" = C3's frame, "book2@1000" = C4 -- and "<workload>@<spp>@<nx>x<ny>" for another frame
+    size: "book2@100@300x300" = the reference's shipped main(), main.rs:323-338) to the pmc_summary.json of the kernel build
+    that is checked in (written by tools/collect_profiles.sh).  The entry of the timed launch's own frame and spp wins; the
+    workload's base entry is the fallback, and valu_roofline then marks the object `extrapolated`."""
     idx = os.path.join(root, "profiles", "current.json")
     if not os.path.exists(idx):
         return None, None
     try:
         cur = json.load(open(idx))
-        rel = (cur.get("%s@%d" % (workload_key, spp)) if spp else None) or cur.get(workload_key)
+        rel = None
+        if spp and frame:
+            rel = cur.get("%s@%d@%dx%d" % (workload_key, spp, frame[0], frame[1]))
+        rel = rel or (cur.get("%s@%d" % (workload_key, spp)) if spp else None) or cur.get(workload_key)
         if not rel:
             return None, None
         path = os.path.join(root, rel)

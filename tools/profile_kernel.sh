@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box): tools/profile_kernel.sh <tag> <workload> <kernel_substr> <samples_per_launch> [bench args...]
+# usage (GPU box): [PROFILE_FRAME="nx ny spp"] tools/profile_kernel.sh <tag> <workload> <kernel_substr> <samples_per_launch> [bench args...]
 # -> gpurun_out/<tag>/{pmc_summary.json, kernel_stats.csv, roofline.json}: what profiles/<round>_<tag>/ holds for one kernel
 tag=$1; wl=$2; kern=$3; samples=$4; shift 4
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O

@@ -39,6 +39,9 @@ def main():
     res["build"] = rl.source_stamp(ROOT)
     res["kernel_names"] = sorted(names)
     res["env_options"] = {k: v for k, v in os.environ.items() if k.startswith("RTG_") or k == "RTIOW_GPU_LIB"}
+    if os.environ.get("PROFILE_FRAME"):   # "nx ny spp" of the profiled launch (tools/profile_kernel.sh): bench.py quotes the counters for that frame only
+        nx, ny, spp = (int(v) for v in os.environ["PROFILE_FRAME"].split())
+        res["frame"] = {"nx": nx, "ny": ny, "spp": spp}
     if 'FETCH_SIZE' in summary and 'WRITE_SIZE' in summary:
         fetch = summary['FETCH_SIZE'] * 1024 * 2   # KiB -> B, gfx950 x2 correction
         write = summary['WRITE_SIZE'] * 1024
