@@ -520,6 +520,12 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
 #else
   uint32_t* slot = g_slots + ((size_t)blockIdx.x * n_waves + wave) * (POOL * POOL_FIELDS);
 #endif
+  // (the cold rows as GLOBAL accesses: through the laundered generic pointer they were flat_load / flat_store, which count
+  // on lgkmcnt too -- every wait for an LDS read in a pass then also waited for the rows' trip to L2)
+  typedef __attribute__((address_space(1))) uint32_t* g_u32_ptr;
+  typedef __attribute__((address_space(1))) float* g_f32_ptr;
+  const g_u32_ptr slot_g = (g_u32_ptr)(uintptr_t)slot;
+  const g_f32_ptr slotf_g = (g_f32_ptr)(uintptr_t)slot;
   float* slotf = reinterpret_cast<float*>(slot);
   uint16_t* tlist = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(s_mem) + staged) + wave * (3u * POOL);
   uint16_t* slist = tlist + POOL;
@@ -530,8 +536,8 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
   // best_pc in LDS: staged programs fit 16 bits ((pc - pc0) / 8; the three markers keep their low 16 bits), others 32
   typedef typename std::conditional<USE_LDS, uint16_t, uint32_t>::type bpc_t;
   bpc_t* lds_bpc = reinterpret_cast<bpc_t*>(reinterpret_cast<float*>(hot_base) + (size_t)n_waves * (POOL * 7u)) + (size_t)wave * POOL;
-#define SLOT_U(f_, j_) slot[(f_)*POOL + (j_)]
-#define SLOT_F(f_, j_) slotf[(f_)*POOL + (j_)]
+#define SLOT_U(f_, j_) slot_g[(f_)*POOL + (j_)]
+#define SLOT_F(f_, j_) slotf_g[(f_)*POOL + (j_)]
 #define RAY_F(f_, j_) (*(HOT_LDS ? &lds_ray[(f_)*POOL + (j_)] : &slotf[(f_)*POOL + (j_)]))
 #ifndef RT_HOT_BEST
 #define RT_HOT_BEST 1  // 0: (best, best_pc) stay in the global slot rows even when the rays are in LDS
@@ -748,10 +754,9 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           const uint32_t s = SLOT_U(PF_SAMPLE, j), xy = SLOT_U(PF_XY, j);
           const float hb = BEST_F(j);
           // ---------------- color() loop body, lib.rs:73-97, for a hit on a scattering material ----------
-          SampleRng rng;
-          rng.init(seed, (P.ny - 1u - (xy >> 16)) * P.nx + (xy & 0xffffu), s);
-          rng.set_event(bounces + 1u);
-          rng.seek(3u * RT_SCATTER_TRIES * tries);  // the attempts earlier passes made (whole Philox blocks: no block is generated here)
+          // The hit record first: it needs LDS data only (ray, best, the winning record, its material), so this arithmetic runs
+          // while the cold rows above (bounces, strength, sample, pixel: one trip to L2) are still on their way; the RNG, which is
+          // keyed by them, comes after.
           const uint4 plo = RT_SPHERE_GEOM(bpc);
           const uint32_t pflags = RT_SPHERE_FLAGS(bpc);
           V3 off = mk(u2f(plo.x), u2f(plo.y), u2f(plo.z));
@@ -765,6 +770,16 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           const uint32_t kind = (pflags >> F_MATKIND_SHIFT) & 7u;  // the flattener's copy of the material kind
           const float param = u2f(mlo.w);
           const V3 mcol = mk(u2f(mlo.x), u2f(mlo.y), u2f(mlo.z));
+          // |d| and unit(d) once for the Metal and the Dielectric lanes of the pass (vec3.rs:59,66): the two
+          // branches below are exclusive, the wave usually runs both, and a sqrt + three divides is what they share
+          float sd_len = 0.f;
+          V3 sd_unit = sd;
+          if (kind == MAT_METAL || kind == MAT_DIELECTRIC) sd_len = vlen(sd), sd_unit = sdiv(sd, sd_len);
+          __builtin_amdgcn_sched_barrier(0);  // (keeps the block above in front of the first use of the cold rows)
+          SampleRng rng;
+          rng.init(seed, (P.ny - 1u - (xy >> 16)) * P.nx + (xy & 0xffffu), s);
+          rng.set_event(bounces + 1u);
+          rng.seek(3u * RT_SCATTER_TRIES * tries);  // the attempts earlier passes made (whole Philox blocks: no block is generated here)
           // lib.rs:76 with emitted = 0 (material.rs:126): accum stays +0, see PoolField
           V3 nd = mk(0.f, 0.f, 0.f), att = mcol;
           bool scattered = true;
@@ -779,11 +794,6 @@ __global__ __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_EU) void ren
           V3 rs = mk(0.f, 0.f, 0.f);
           if (kind != MAT_DIELECTRIC) deferred = !in_unit_sphere_tries(rng, (RT_SCATTER_TRIES && tries < 3u) ? (uint32_t)RT_SCATTER_TRIES : 0xffffffffu, rs);
           if (COUNT && !deferred) cnt.shaded++;
-          // |d| and unit(d) once for the Metal and the Dielectric lanes of the pass (vec3.rs:59,66): the two
-          // branches below are exclusive, the wave usually runs both, and a sqrt + three divides is what they share
-          float sd_len = 0.f;
-          V3 sd_unit = sd;
-          if (kind == MAT_METAL || kind == MAT_DIELECTRIC) sd_len = vlen(sd), sd_unit = sdiv(sd, sd_len);
           if (kind == MAT_LAMBERTIAN) {  // material.rs:57-65
             V3 target = vadd(vadd(hp, hn), rs);
             nd = vsub(target, hp);
