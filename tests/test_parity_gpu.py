@@ -605,3 +605,53 @@ def test_bvh4_mode_renders_the_same_image(pkg, gpu, oracle):
     w2, _, _ = pkg.scenes.cornell_box_scene(b2, 30, 30)
     with pytest.raises(pkg.capi.RtError):
         b2.scene(w2).set_option("bvh4", 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("small_frames", [0, 1])
+def test_small_frame_launch_geometry_never_changes_a_bit(pkg, gpu, oracle, small_frames, capfd):
+    """rtg_launch.inc pool_geometry: a frame with fewer work items than the chip has lanes runs as small workgroups with one
+    work item per lane (reservations of 64 instead of 256); option small_frames = 0 keeps one geometry for every size.  Either
+    way the bits are the oracle's -- the reference's own benchmark frame (benches/scene.rs: 10 x 10 x 4) included -- on the
+    full-feature pool kernel (bench), the lean one (book1) and the lock-step one (cornell), production and instrumented variant."""
+    for name, nx, ny, ns in (("bench", 10, 10, 4), ("bench", 40, 24, 3), ("book1", 10, 10, 4), ("book1", 100, 60, 2),
+                             ("cornell", 24, 24, 5), ("book2", 16, 16, 6)):
+        sg, cam_g, _, _, _ = build_case(pkg, gpu, name, nx, ny)
+        so, cam_o, _, _, _ = build_case(pkg, oracle, name, nx, ny)
+        sg.set_option("small_frames", small_frames)
+        sg.set_option("verbose", 1)
+        img_o, st_o = so.par_cast(cam_o, nx, ny, ns, stats=True)
+        capfd.readouterr()
+        img_p = sg.par_cast(cam_g, nx, ny, ns)
+        err = capfd.readouterr().err
+        sg.set_option("verbose", 0)
+        if name in ("bench", "book1", "book2"):   # the pool kernels report their launch geometry
+            assert ("x 1024 threads" in err) == (small_frames == 0), (name, nx, ny, err)
+        img_g, st_g = sg.par_cast(cam_g, nx, ny, ns, stats=True)
+        assert_bit_equal(img_p, img_o, "%s %dx%dx%d production, small_frames %d" % (name, nx, ny, ns, small_frames))
+        assert_bit_equal(img_g, img_o, "%s %dx%dx%d instrumented, small_frames %d" % (name, nx, ny, ns, small_frames))
+        for k in ("samples", "aabb_tests", "prim_tests", "shaded_hits", "rays", "draws"):
+            assert st_g[k] == st_o[k], (name, small_frames, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("share", [0, 1])
+def test_drain_work_sharing_never_changes_a_bit(pkg, gpu, oracle, share):
+    """rt_pool_full.h RT_DRAIN_SHARE: once the work queue is empty, waves that have run dry adopt rays from waves that still
+    hold some (a path's RNG streams are keyed by pixel, sample and event: which wave runs it is invisible).  Frames large
+    enough for every wave of a workgroup to hold paths when the queue runs dry, with the deep bounce cap that makes the
+    drain long; sharing on and off, shards included."""
+    for name, nx, ny, ns, mb in (("book2", 96, 96, 24, 50), ("book2_bvh", 64, 64, 16, 50), ("volume_bvh", 96, 64, 12, 50),
+                                 ("bench", 128, 96, 10, 12)):
+        sg, cam_g, _, _, _ = build_case(pkg, gpu, name, nx, ny)
+        so, cam_o, _, _, _ = build_case(pkg, oracle, name, nx, ny)
+        sg.set_option("donate_max", share)
+        sg.set_option("small_frames", 0)   # 16-wave workgroups: sharing is between the waves of a workgroup
+        img_o, st_o = so.par_cast(cam_o, nx, ny, ns, stats=True, max_bounces=mb)
+        img_g, st_g = sg.par_cast(cam_g, nx, ny, ns, stats=True, max_bounces=mb)
+        assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns, max_bounces=mb), img_o, "%s production, sharing %d" % (name, share))
+        assert_bit_equal(img_g, img_o, "%s instrumented, sharing %d" % (name, share))
+        for k in ("samples", "aabb_tests", "prim_tests", "shaded_hits", "rays", "draws"):
+            assert st_g[k] == st_o[k], (name, share, k)
+        assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns, rank=2, nranks=3, max_bounces=mb),
+                         so.par_cast(cam_o, nx, ny, ns, rank=2, nranks=3, max_bounces=mb), "%s shard, sharing %d" % (name, share))
