@@ -42,3 +42,7 @@ python tools/latency_probe.py > $O/latency_probe.txt 2>&1
 python tools/shard_time.py > $O/shard_time.txt 2>&1
 python -m pytest tests -m gpu -q --timeout=300 > $O/pytest_gpu.log 2>&1
 ls -la $O
+# where the waves wait (tools/pmc_wait.sh): issue / wait-to-issue / s_waitcnt shares of the wave-cycles, per instruction class
+tools/pmc_wait.sh gpurun_out/$tag/wait_book1 > $O/wait_attribution_book1.txt 2>&1
+tools/pmc_wait.sh gpurun_out/$tag/wait_book2 --workload book2 --spp 100 > $O/wait_attribution_book2.txt 2>&1
+rm -rf $O/wait_book1 $O/wait_book2
