@@ -188,7 +188,7 @@ struct ChunkMode {
   // reservation would leave most waves without work and make the others run four generations one after another
   // (rtg_launch.inc pool_geometry).  pix_work is a multiple of 256, so a reservation never straddles a chunk.
   uint32_t work_block;
-  uint32_t donate_max;  // full-feature pool kernel: drain-phase work sharing (rt_pool_full.h RT_DRAIN_SHARE), 0 = off
+  uint32_t drain_share;  // full-feature pool kernel: drain-phase work sharing (rt_pool_full.h RT_DRAIN_SHARE), 0 = off
 };
 RT_DEV uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 

@@ -540,7 +540,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
       }
       if (COUNT) t_mark2 = RT_TICK();
 #if RT_DRAIN_SHARE
-      if (exhausted && load_const(&lc->cm.donate_max) != 0u) {  // ---- drain-phase work sharing (see DrainCtl) ----
+      if (exhausted && load_const(&lc->cm.drain_share) != 0u) {  // ---- drain-phase work sharing (see DrainCtl) ----
         const uint32_t copy_rows = (COUNT && tr_out) ? (uint32_t)TQ_FIELDS : (uint32_t)TQ_TRACE;
         uint32_t* dq = uniform_ptr(g_slots + (size_t)blockIdx.x * wg_words + (size_t)n_waves * (FPOOL * FPOOL_FIELDS));
         if (n_dead == FPOOL) {  // run dry: register as hungry, adopt what waits on the workgroup's stack
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
       RT_TL_SERVICE();
       if (n_dead == FPOOL) {
 #if RT_DRAIN_SHARE
-        if (load_const(&lc->cm.donate_max) != 0u) {  // leave when every wave of the workgroup has run dry and nothing waits to be adopted
+        if (load_const(&lc->cm.drain_share) != 0u) {  // leave when every wave of the workgroup has run dry and nothing waits to be adopted
           if (hungry && __builtin_amdgcn_readfirstlane(pool_lds_ld(ctl + DC_HUNGRY)) == n_waves &&
               __builtin_amdgcn_readfirstlane(pool_lds_ld(ctl + DC_COUNT)) == 0u) break;
           __builtin_amdgcn_s_sleep(127);  // (poll every ~3.5 us)

@@ -15,6 +15,7 @@
 #include <mutex>
 #include <functional>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/rtiow_gpu.h"
@@ -109,10 +110,8 @@ struct rtg_scene {
   int wg_per_cu = 0;                       // 0 = ask the occupancy API
   int full_threads = 0;                    // full-feature pool kernel: 0 = the variant's maximum (RTG_BLOCK overrides)
   int pool_threads = 0;                    // lean ray-pool kernel: 0 = ONE 16-wave workgroup per CU shares one LDS copy of the program (RTG_BLOCK overrides)
-  int donate_max = 1;                      // pool kernels, drain-phase work sharing (rt_pool_full.h RT_DRAIN_SHARE): 0 = off
+  int drain_share = 1;                      // pool kernels, drain-phase work sharing (rt_pool_full.h RT_DRAIN_SHARE): 0 = off
   int small_frames = 1;                    // rtg_launch.inc pool_geometry: frames smaller than the chip get small workgroups and reservations
-  struct KernelSetup { const void* kernel; int bt; size_t lds; int per_cu; };
-  std::vector<KernelSetup> kernel_setups;  // (kernel, block, LDS) triples whose attributes are set (rtg_launch.inc kernel_setup)
   LaunchCtx ctx[RTG_MAX_FRAMES];           // frames in flight
   int n_ctx = 1, next_ctx = 0;
   LaunchCtx* cx = &ctx[0];                 // the context of the call being made (ctx_acquire)
@@ -538,7 +537,7 @@ int rtg_scene_set_option(rtg_scene* s, const char* name, int value) {
     s->pool_threads = s->full_threads = value;
   }
   else if (k == "wg_per_cu") s->wg_per_cu = value;
-  else if (k == "donate_max") s->donate_max = value;
+  else if (k == "drain_share") s->drain_share = value;
   else if (k == "small_frames") s->small_frames = value;        // 0: one geometry for every frame size (measurement switch)
   else if (k == "verbose") s->verbose = value;                  // print launch geometry / schedule statistics to stderr
   else if (k == "window") s->window = value;                    // full-feature kernel: records staged in LDS, -1 = automatic

@@ -645,7 +645,7 @@ def test_drain_work_sharing_never_changes_a_bit(pkg, gpu, oracle, share):
                                  ("bench", 128, 96, 10, 12)):
         sg, cam_g, _, _, _ = build_case(pkg, gpu, name, nx, ny)
         so, cam_o, _, _, _ = build_case(pkg, oracle, name, nx, ny)
-        sg.set_option("donate_max", share)
+        sg.set_option("drain_share", share)
         sg.set_option("small_frames", 0)   # 16-wave workgroups: sharing is between the waves of a workgroup
         img_o, st_o = so.par_cast(cam_o, nx, ny, ns, stats=True, max_bounces=mb)
         img_g, st_g = sg.par_cast(cam_g, nx, ny, ns, stats=True, max_bounces=mb)
@@ -655,3 +655,21 @@ def test_drain_work_sharing_never_changes_a_bit(pkg, gpu, oracle, share):
             assert st_g[k] == st_o[k], (name, share, k)
         assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns, rank=2, nranks=3, max_bounces=mb),
                          so.par_cast(cam_o, nx, ny, ns, rank=2, nranks=3, max_bounces=mb), "%s shard, sharing %d" % (name, share))
+
+
+@pytest.mark.gpu
+def test_frames_of_different_lds_needs_alternate_on_one_kernel(pkg, gpu, oracle):
+    """The dynamic-LDS cap of a kernel belongs to the function, not to a scene handle or a frame size, and the last
+    hipFuncSetAttribute wins: a small frame (a 64-thread workgroup asks the lean kernel for half the LDS of a 1024-thread one)
+    between two large ones, and a second scene on the same kernel, must not lower it under the next large launch."""
+    sg, cam_g, _, _, _ = build_case(pkg, gpu, "book1", 512, 384)
+    so, cam_o, _, _, _ = build_case(pkg, oracle, "book1", 512, 384)
+    sg2, cam_g2, _, _, _ = build_case(pkg, gpu, "book1_sah", 16, 16)
+    so2, cam_o2, _, _, _ = build_case(pkg, oracle, "book1_sah", 16, 16)
+    big = so.par_cast(cam_o, 512, 384, 3)     # 589 824 work items: every lane busy, 1024-thread workgroups
+    cs_g = gpu.camera_look(pkg.scenes.v(13, 2, 3), pkg.scenes.v(0, 0, 0), pkg.scenes.v(0, 1, 0), 20.0, 1.0, 0.1, 10.0)
+    small = so.par_cast(cs_g, 16, 16, 2)      # 512 work items: 64-thread workgroups
+    for _ in range(2):
+        assert_bit_equal(sg.par_cast(cam_g, 512, 384, 3), big, "large frame")
+        assert_bit_equal(sg.par_cast(cs_g, 16, 16, 2), small, "small frame on the same handle")
+        assert_bit_equal(sg2.par_cast(cam_g2, 16, 16, 2), so2.par_cast(cam_o2, 16, 16, 2), "another scene on the same kernel")
