@@ -36,6 +36,18 @@ namespace rtg {
 #ifndef RT_DRAIN_ALL
 #define RT_DRAIN_ALL 1  // a starved wave runs the partial passes of ALL its stacks before it refills
 #endif
+// Wave priorities (s_setprio; the arbiter of a SIMD prefers the wave with the higher one).  The four waves of a SIMD are in
+// different phases at any moment; what a phase is worth to the others differs: a SLOW PASS holds parked lanes back (every lane
+// of the wave that stands at a non-BOX record waits for it), a box run feeds them, a service (shade / camera passes, stack
+// traffic: long dependent chains with trips to L2 in them) has the slack.  Slow passes first, box runs next, services last:
+// book-2 800x800x100 40.0 -> 38.7 ms, 400 spp 146.6 -> 143.3, the reference's 300x300x100 frame 10.4 -> 9.8, book2_bvh 43.3 ->
+// 42.2 (profiles/r04_experiments/r04s_priority_*; services first: 0 on book-2, -2 % on the lean kernel, which loses with every
+// assignment tried and keeps none).
+#ifndef RT_FULL_SERVICE_PRIO
+#define RT_FULL_SERVICE_PRIO 0
+#define RT_FULL_BOX_PRIO 1
+#define RT_FULL_SLOW_PRIO 3
+#endif
 #ifndef RT_FULL_BOX_UNROLL
 #define RT_FULL_BOX_UNROLL 2  // box steps per schedule check (book-2 43.8 -> 43.0 ms)
 #endif
@@ -256,6 +268,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
     const uint32_t n_fin = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op == OP_END));
     const bool can_serve = (t_count + tn_count) != 0u || s_count + n_fin >= 64u || (TEX && x_count + n_fin >= 64u);
     if ((64u - n_busy >= tune.refill_min && can_serve) || n_busy == 0) {
+      __builtin_amdgcn_s_setprio(RT_FULL_SERVICE_PRIO);
       if (COUNT) t_mark = RT_TICK();
       {  // (1) finish (depth is 0 again, so o / d are the ray's own)
         const bool fin = have_ray && op == OP_END;
@@ -613,6 +626,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
       if (COUNT) t_refill += RT_TICK() - t_mark2;
       if (COUNT) t_serv += RT_TICK() - t_mark;
       RT_TL_SERVICE();
+      __builtin_amdgcn_s_setprio(RT_FULL_BOX_PRIO);
       if (n_dead == FPOOL) {
 #if RT_DRAIN_SHARE
         if (load_const(&lc->cm.drain_share) != 0u) {  // leave when every wave of the workgroup has run dry and nothing waits to be adopted
@@ -632,7 +646,9 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
     for (;;) {
 #define RT_R_PIXEL ((load_const(&lc->P.ny) - 1u - (r_xy >> 16)) * load_const(&lc->P.nx) + (r_xy & 0xffffu))
 #define RT_R_EVENT (r_bounces + 1u)
+#define RT_PHASE_PRIO 1  // (the pool schedule sets wave priorities per phase: see RT_FULL_SLOW_PRIO)
 #include "rt_full_traverse.inc"
+#undef RT_PHASE_PRIO
 #undef RT_R_PIXEL
 #undef RT_R_EVENT
     op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;

@@ -76,6 +76,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   for (;;) {
     // ============================== SHADE / GEN (every lane, its own path) ==========================
     {
+      __builtin_amdgcn_s_setprio(RT_FULL_SERVICE_PRIO);  // (Cornell 3.37 -> 3.21 ms, smoke boxes 6.7 -> 6.35, volume_test 4.15 -> 4.0: r04s_priority_sync_ab.txt)
       if (COUNT) t_mark = RT_TICK();
       const DevParams P = load_const(&lc->P);
       const ChunkMode cm = load_const(&lc->cm);
@@ -238,7 +239,9 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
     for (;;) {
 #define RT_R_PIXEL r_pixel
 #define RT_R_EVENT r_event
+#define RT_PHASE_PRIO 1  // wave priorities per phase (rt_pool_full.h RT_FULL_SLOW_PRIO): slow passes 3, box runs 1, the SHADE / GEN phase 0
 #include "rt_full_traverse.inc"
+#undef RT_PHASE_PRIO
 #undef RT_R_PIXEL
 #undef RT_R_EVENT
     op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
