@@ -4,7 +4,10 @@
 // PARITY UNPINNED: the reference (cbiffle/rtiow-rust) is Rust, cannot be compiled in this image
 // (no rustc/cargo, crates not vendored) and holds no golden vectors / known-answer tests for the
 // color() hot path.  This oracle is a line-by-line CPU restatement of the
-// reference arithmetic; each function cites the reference file:line it follows.
+// reference arithmetic; each function cites the reference file:line it follows.  What IS pinned against the reference:
+// the two pictures it publishes (img/demo-scene.jpg, img/rttnw-final.jpg) correlate with this oracle's renders of the
+// same seeded scenes at 0.99 / 0.92 (tests/test_reference_image.py) -- scene construction, RNG stream, camera and
+// geometry, not low-order bits.
 //
 // rto_core.hpp: Vec3 / Ray / Aabb math, RNG front-ends and the shared libm restatements.
 #pragma once

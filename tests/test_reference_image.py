@@ -47,3 +47,39 @@ def test_oracle_render_matches_the_reference_readme_image(pkg, oracle):
 @pytest.mark.gpu
 def test_gpu_render_matches_the_reference_readme_image(pkg, gpu):
     check(pkg, gpu, 1000)
+
+
+# ---- the reference's OTHER published picture: img/demo-scene.jpg = the book-1 random-spheres scene, i.e. the scene of the
+# headline workload (BASELINE.json configs[1] / [2]).  tests/golden/ref_demo_scene_300x200.npz is that JPEG box-filtered to
+# 300x200 (tools/gen_ref_image_fixture.py).  It was rendered by an older revision (gradient sky instead of our sky-dome emitter),
+# so levels are not compared either -- but the ~480 small spheres on the ground sit where, and have the materials and colours
+# that, `random_scene` (src/lib.rs:236-319) draws from SmallRng::seed_from_u64(0xDEADBEEF): our transliteration with the emulated
+# stream correlates with the reference's picture at 0.99 (0.98 on the ground alone); any other construction seed gives 0.6 overall
+# (camera, big spheres, horizon) and 0.0-0.25 on the ground.  That pins, against an OUTPUT OF THE REFERENCE, the seed expansion,
+# Pcg64Mcg, gen::<f32>() / gen::<Vec3>(), the draw ORDER of the scene builder and the camera of the workload bench.py times.
+NX2, NY2 = 300, 200
+
+
+def render_book1_u8(pkg, backend, seed, ns):
+    b = backend.builder()
+    world, cam, _ = pkg.scenes.random_scene(b, NX2, NY2, rng=pkg.small_rng.SmallRng(seed))
+    return pkg.ppm.to_u8(b.scene(world).par_cast(cam, NX2, NY2, ns)).astype(np.float32)
+
+
+def check_book1(pkg, backend, ns):
+    ref = np.load(os.path.join(GOLD, "ref_demo_scene_300x200.npz"))["rgb"].astype(np.float32)
+    ground = slice(NY2 * 55 // 100, NY2)                # below the horizon: the field of small random spheres
+    ours = render_book1_u8(pkg, backend, 0xDEADBEEF, ns)
+    assert corr(ours, ref) > 0.97 and corr(ours[ground], ref[ground]) > 0.95
+    for other in (0xDEADBEEE, 1):
+        ctl = render_book1_u8(pkg, backend, other, ns)
+        assert corr(ctl, ref) < 0.75 and corr(ctl[ground], ref[ground]) < 0.45
+
+
+def test_oracle_book1_render_matches_the_reference_demo_image(pkg, oracle):
+    check_book1(pkg, oracle, 16)
+
+
+@pytest.mark.gpu
+def test_gpu_book1_render_matches_the_reference_demo_image(pkg, gpu):
+    check_book1(pkg, gpu, 200)
