@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Drain timeline of a pool kernel (GPU box, a -DRT_TIMELINE build of the library: tools/build_variant.sh tl -DRT_TIMELINE, then
 RTIOW_GPU_LIB=.../variants/tl.so): per-wave records of rt_pool.h RT_TL_* -- when each wave sees the work queue empty, when its
-pool thins out, when it is done, what it did in between.  usage: timeline.py [case nx ny ns [max_bounces]]"""
+pool thins out, when it is done, what it did in between.  usage: timeline.py [case nx ny ns [max_bounces [rank nranks]]]"""
 import ctypes as C, os, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,6 +12,7 @@ pkg = g.load_package(); gpu = pkg.load(); capi = pkg.capi
 a = sys.argv[1:]
 case, nx, ny, ns = (a[0], int(a[1]), int(a[2]), int(a[3])) if len(a) >= 4 else ("book1", 1200, 800, 50)
 mb = int(a[4]) if len(a) > 4 else 50
+rank, nranks = (int(a[5]), int(a[6])) if len(a) > 6 else (0, 1)
 path = os.path.join(tempfile.gettempdir(), "rtg_timeline.bin")
 os.environ["RTG_TIMELINE_OUT"] = path
 sc, cam, _, _, _ = build_case(pkg, gpu, case, nx, ny)
@@ -19,7 +20,7 @@ out = np.zeros((ny, nx, 3), dtype=np.float32)
 
 
 def run():
-    p = capi.make_params(nx, ny, ns, max_bounces=mb)
+    p = capi.make_params(nx, ny, ns, max_bounces=mb, rank=rank, nranks=nranks)
     st = capi.Stats(); st.struct_size = C.sizeof(capi.Stats)
     gpu.check(gpu._par_cast(sc.h, C.byref(cam), C.byref(p), out.ctypes.data_as(capi.c_f32p), C.byref(st)))
     return st.kernel_ms
