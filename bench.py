@@ -205,7 +205,7 @@ def main():
 
     def step(flags=0):
         def render_shard(fb_, rank_, world_):
-            p = pkg.make_params(nx, ny, spp, seed=args.seed, rank=rank_, nranks=world_, flags=flags)
+            p = pkg.make_params(nx, ny, spp, seed=args.seed, rank=rank_, nranks=world_, flags=flags, tile_w=frame.tile[0], tile_h=frame.tile[1])
             return scene.par_cast_device(cam, p, ctypes.c_void_p(fb_.data_ptr()), stream, want_stats=True)
         return frame.render(render_shard)   # zero, this rank's tiles, ONE reduce(sum) to rank 0
 
@@ -311,11 +311,11 @@ def main():
         if world == 1:
             shard_txt = "none"
         elif args.scaling == "strong" or args.spp:
-            shard_txt = ("the FIXED %dx%dx%d frame, interleaved 16x16 pixel tiles (tile %% %d == rank): strong scaling; ONE RCCL "
-                         "reduce(sum) of the float3 framebuffer to rank 0 per frame" % (nx, ny, spp, world))
+            shard_txt = ("the FIXED %dx%dx%d frame, interleaved %dx%d pixel tiles (tile %% %d == rank): strong scaling; ONE RCCL "
+                         "reduce(sum) of the float3 framebuffer to rank 0 per frame" % (nx, ny, spp, frame.tile[0], frame.tile[1], world))
         else:
-            shard_txt = ("interleaved 16x16 pixel tiles (tile %% %d == rank), spp = %d*N: weak scaling; ONE RCCL reduce(sum) "
-                         "of the float3 framebuffer to rank 0 per frame" % (world, wspp))
+            shard_txt = ("interleaved %dx%d pixel tiles (tile %% %d == rank), spp = %d*N: weak scaling; ONE RCCL reduce(sum) "
+                         "of the float3 framebuffer to rank 0 per frame" % (frame.tile[0], frame.tile[1], world, wspp))
         line = {
             "metric": "Msamples/s (pixels*spp/s), %s %dx%d" % (
                 {"book1": "book-1 random-spheres", "book2": "book-2 final scene", "cornell": "Cornell box"}[args.workload], nx, ny),

@@ -63,7 +63,7 @@ typedef struct rtg_params {
   /* Pixel sharding for multi-GPU (one process per GPU): the image is cut into tile_w x tile_h
    * tiles numbered row-major from the top-left; this call renders tiles with
    * tile_index % nranks == rank and leaves every other pixel of `out` untouched. */
-  uint32_t tile_w, tile_h; /* 0 -> 16                                                         */
+  uint32_t tile_w, tile_h; /* multiples of 8; 0 -> 16                                         */
   uint32_t rank, nranks;   /* nranks 0 -> 1                                                   */
   uint32_t flags;          /* RTG_FLAG_*                                                      */
   uint32_t reserved;

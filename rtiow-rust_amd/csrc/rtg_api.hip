@@ -590,7 +590,7 @@ static int check_params(const rtg_scene* s, const rtg_camera* camera, const rtg_
   d.seed_lo = (uint32_t)p->seed, d.seed_hi = (uint32_t)(p->seed >> 32);
   d.tile_w = p->tile_w ? p->tile_w : 16u;
   d.tile_h = p->tile_h ? p->tile_h : 16u;
-  if (d.tile_w % 16u || d.tile_h % 16u) return fail(RTG_ERR_INVALID, "tile_w / tile_h must be multiples of 16");
+  if (d.tile_w % 8u || d.tile_h % 8u) return fail(RTG_ERR_INVALID, "tile_w / tile_h must be multiples of 8");
   d.nranks = p->nranks ? p->nranks : 1u;
   d.rank = p->rank;
   if (d.rank >= d.nranks) return fail(RTG_ERR_INVALID, "rank >= nranks");

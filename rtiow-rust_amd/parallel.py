@@ -1,7 +1,7 @@
 """Multi-GPU sharding of par_cast: one process per GPU, pixels (not samples) partitioned.
 
 The per-pixel mean is an ORDERED left fold over samples (lib.rs:365-374), so splitting samples across
-GPUs would change the f32 addition order; pixels are independent, so the image is cut into 16x16 tiles and
+GPUs would change the f32 addition order; pixels are independent, so the image is cut into tiles (shard_tile) and
 rank r renders the tiles with tile_index % world == r (rtg_params.rank/nranks).  Every rank writes its
 pixels into a zero-filled full-frame buffer; ONE collective -- reduce(sum) to rank 0 over RCCL/xGMI --
 assembles the frame.  x + 0 is exact, so the result is bit-identical to the single-GPU frame.
@@ -12,6 +12,14 @@ library is rtg_par_cast_multi (include/rtiow_gpu.h).
 """
 import torch
 import torch.distributed as dist
+
+
+def shard_tile(world):
+    """(tile_w, tile_h) of the interleave for `world` ranks: 16x16 up to 4 ranks, 8x8 from 8 ranks on.  With an eighth of the
+    tiles per rank the slowest rank of the 16x16 interleave lies 5-6 % above the mean (every shard of C3's and of a C5-like
+    frame timed alone: profiles/r04_experiments/r04x_shard_tiles.txt); 8x8 tiles bring book-1's to 1.6-2 % (slowest shard 10.57
+    -> 10.18 ms) and book-2's to 4 % (29.2 -> 28.9); at 2 and 4 ranks the tile size changes nothing."""
+    return (8, 8) if world >= 8 else (16, 16)
 
 
 def world_info():
@@ -29,6 +37,7 @@ class ShardedFrame:
 
     def __init__(self, nx, ny, device, via_host=False):
         self.rank, self.world = world_info()
+        self.tile = shard_tile(self.world)   # pass as rtg_params.tile_w / tile_h
         self.fb = torch.zeros((ny, nx, 3), dtype=torch.float32, device=device)
         self.via_host = via_host
 

@@ -673,3 +673,31 @@ def test_frames_of_different_lds_needs_alternate_on_one_kernel(pkg, gpu, oracle)
         assert_bit_equal(sg.par_cast(cam_g, 512, 384, 3), big, "large frame")
         assert_bit_equal(sg.par_cast(cs_g, 16, 16, 2), small, "small frame on the same handle")
         assert_bit_equal(sg2.par_cast(cam_g2, 16, 16, 2), so2.par_cast(cam_o2, 16, 16, 2), "another scene on the same kernel")
+
+
+@pytest.mark.gpu
+def test_tiles_of_8_pixels_shard_like_tiles_of_16(pkg, gpu, oracle):
+    """rtg_params.tile_w / tile_h may be any multiples of 8 (8x16 tiles balance 8 ranks better than 16x16: parallel.shard_tile).
+    A rank's tiles then need not add up to whole 256-item reservations (the work-item count is padded; the padding lies outside
+    the image) and a 16x16 block of the baseline kernel spans several tiles.  Every kernel, ragged image sizes, shard by shard
+    against the oracle, and the shards sum to the unsharded frame."""
+    for name, nx, ny, ns, env in (("book1", 100, 60, 5, {}), ("book2", 72, 40, 4, {}), ("cornell", 50, 50, 6, {}),
+                                  ("book1", 90, 52, 3, {"kernel": 1}), ("bench", 44, 36, 7, {})):
+        sg, cam_g, _, _, _ = build_case(pkg, gpu, name, nx, ny)
+        so, cam_o, _, _, _ = build_case(pkg, oracle, name, nx, ny)
+        for k, v in env.items():
+            sg.set_option(k, v)
+        whole = so.par_cast(cam_o, nx, ny, ns)
+        for tw, th, n in ((8, 8, 3), (8, 16, 8), (24, 8, 5)):
+            acc = np.zeros_like(whole)
+            for r in range(n):
+                kw = {"tile_w": tw, "tile_h": th, "rank": r, "nranks": n}
+                part = sg.par_cast(cam_g, nx, ny, ns, **kw)
+                assert_bit_equal(part, so.par_cast(cam_o, nx, ny, ns, **kw), "%s %s" % (name, kw))
+                acc += part
+            assert_bit_equal(acc, whole, "%s: %d shards of %dx%d tiles summed" % (name, n, tw, th))
+        img_g, st_g = sg.par_cast(cam_g, nx, ny, ns, stats=True, tile_w=8, tile_h=16, rank=1, nranks=2)
+        img_o, st_o = so.par_cast(cam_o, nx, ny, ns, stats=True, tile_w=8, tile_h=16, rank=1, nranks=2)
+        assert_bit_equal(img_g, img_o, name + " instrumented, 8x16 tiles")
+        for k in ("samples", "aabb_tests", "prim_tests", "shaded_hits", "rays", "draws"):
+            assert st_g[k] == st_o[k], (name, k)

@@ -1,4 +1,4 @@
-"""Kernel time of the shards of an N-rank frame (16x16 pixel tiles interleaved by rank: what `bench.py --gpus N` and
+"""Kernel time of the shards of an N-rank frame (pixel tiles interleaved by rank, 16x16 up to 4 ranks and 8x8 from 8 on: what `bench.py --gpus N` and
 rtg_par_cast_multi give each GPU), each measured ALONE on ONE GPU -- a projection of the per-GPU time of a multi-GPU run
 (the slowest shard + the framebuffer reduce), not a multi-GPU measurement.  usage (GPU box): python tools/shard_time.py"""
 import ctypes as C, os, sys
@@ -8,12 +8,14 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as g
 from scene_cases import build_case
 pkg = g.load_package(); gpu = pkg.load(); capi = pkg.capi
+from rtiow_rust_amd import parallel
 
 
 def shard_ms(sc, cam, nx, ny, ns, rank, nranks, out):
     best = 1e9
     for _ in range(3):
-        p = capi.make_params(nx, ny, ns, rank=rank, nranks=nranks)
+        tw, th = parallel.shard_tile(nranks)   # the interleave bench.py --gpus N uses
+        p = capi.make_params(nx, ny, ns, rank=rank, nranks=nranks, tile_w=tw, tile_h=th)
         st = capi.Stats(); st.struct_size = C.sizeof(capi.Stats)
         gpu.check(gpu._par_cast(sc.h, C.byref(cam), C.byref(p), out.ctypes.data_as(capi.c_f32p), C.byref(st)))
         best = min(best, st.kernel_ms)
