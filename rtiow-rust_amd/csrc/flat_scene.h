@@ -43,12 +43,19 @@ enum Op : uint32_t {
   OP_BEND = 8,    // hi = (-, -, medium_pc, op): end of the record stream of a MEDIUM whose boundary is an object graph
                   //      (F_GENERAL_BOUNDARY).  The main walk never reaches it (MEDIUM.end_pc points behind it); a walk that
                   //      runs the boundary's stream as a range query (rt_pool_full.h GENB) finishes the query here.
+  OP_SEG = 9,     // hi = (-, -, skip_pc, op): in front of the hoisted SEGMENT of a list world -- a run of consecutive top-level plain
+                  //      primitives (SPHERE incl. F_MOVE + its OP_EXT, RECT, PRISM), the records up to skip_pc.  What such a primitive returns
+                  //      for a ray does not depend on the hits found so far except through `t < t_range.end` (object.rs:99,195), and a
+                  //      later hit needs a strictly smaller t (lib.rs:41-44), so the run's result is "its closest candidate, first wins,
+                  //      if closer than what was found before it".  A kernel that evaluates the candidate when the ray is CREATED
+                  //      (rt_pool_full.h hoist_eval: full-width, every lane on the same record) commits it here and continues at
+                  //      skip_pc; every other interpreter steps over this record and executes the run.  Same tests, same closest hit.
   // Only in programs with FEAT_DEEP (graph shapes the scheduled kernels do not walk; the general walk of rt_trace.h does):
-  OP_SAVE = 9,    // in front of the stream of an `And` that sits below a Bvh and holds a ConstantMedium: remember the hit so far
-  OP_EXT = 11,    // data-only continuation of the record in front of it (a SPHERE with F_MOVE: lo = motion.xyz); never executed:
-                  // the record that owns it steps over it
-  OP_MERGE = 10,  // behind it: bvh.rs:104-112 for that leaf -- the earlier hit `hl` wins when hl.t < hr.t (only a medium can
+  OP_SAVE = 10,   // in front of the stream of an `And` that sits below a Bvh and holds a ConstantMedium: remember the hit so far
+  OP_MERGE = 11,  // behind it: bvh.rs:104-112 for that leaf -- the earlier hit `hl` wins when hl.t < hr.t (only a medium can
                   // return t >= t_range.end; inside the And itself the later hit replaces, object.rs:403-409)
+  OP_EXT = 12,    // data-only continuation of the record in front of it (a SPHERE with F_MOVE: lo = motion.xyz); never executed:
+                  // the record that owns it steps over it
 };
 
 // flag bits in hi.w above the 8-bit opcode

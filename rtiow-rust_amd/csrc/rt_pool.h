@@ -291,6 +291,8 @@ struct LaunchConsts {
   DevParams P;
   ChunkMode cm;
   PixMap pm;
+  uint32_t seg_first, seg_end;  // full-feature pool kernel: the records of the hoisted segment as program counters (flat_scene.h OP_SEG);
+                                // seg_end = 0: no segment, or hoisting switched off -- OP_SEG is then stepped over
 };
 typedef const __attribute__((address_space(4))) uint32_t* const_u32_ptr;
 template <typename T>
@@ -426,7 +428,7 @@ RT_DEV bool hi_is_root(uint4 hi) { return (hi.w & F_BVH_ROOT) != 0u; }
 constexpr uint32_t RSZ = 32u;
 RT_DEV uint4 fetch_hi_global(const DevScene& sc, uint32_t idx) {  // pc-scaled skip pointers, global-memory variants
   uint4 h = sc.hi[idx];
-  if ((h.w & 0xffu) == OP_BOX) h.z *= RSZ;
+  if ((h.w & 0xffu) == OP_BOX || (h.w & 0xffu) == OP_SEG) h.z *= RSZ;
   if ((h.w & 0xffu) == OP_MEDIUM) h.x *= RSZ;  // end of the boundary's stream
   return h;
 }

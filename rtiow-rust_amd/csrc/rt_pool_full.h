@@ -48,12 +48,17 @@ namespace rtg {
 #define RT_FULL_BOX_PRIO 1
 #define RT_FULL_SLOW_PRIO 3
 #endif
+#ifndef RT_FAT_LEAF
+#define RT_FAT_LEAF 0  // rt_full_traverse.inc
+#endif
 #ifndef RT_FULL_BOX_UNROLL
 #define RT_FULL_BOX_UNROLL 2  // box steps per schedule check (book-2 43.8 -> 43.0 ms)
 #endif
 constexpr uint32_t FPOOL = RT_FULL_POOL_SLOTS;  // paths in flight per wave of the full-feature kernel = capacity of each stack
 enum FullTField : uint32_t {  // T stack: a ray ready to traverse (the *_TRACE rows only exist for the instrumented variant)
-  TQ_O = 0, TQ_D = 3, TQ_TIME = 6, TQ_STRENGTH = 7, TQ_BOUNCES = 10, TQ_SAMPLE = 11, TQ_XY = 12, TQ_TRACE = 13, TQ_FIELDS = 16,
+  TQ_O = 0, TQ_D = 3, TQ_TIME = 6, TQ_STRENGTH = 7, TQ_BOUNCES = 10, TQ_SAMPLE = 11, TQ_XY = 12,
+  TQ_SEG_T = 13, TQ_SEG_PC = 14,  // the hoisted segment's closest candidate for this ray (hoist_eval; flat_scene.h OP_SEG)
+  TQ_TRACE = 15, TQ_FIELDS = 18,
 };
 enum FullSField : uint32_t {  // S / X stacks: a finished ray with its hit record
   SQ_P = 0, SQ_N = 3, SQ_D = 6, SQ_TIME = 9, SQ_HITMAT = 10, SQ_EVDRAWS = 11, SQ_STRENGTH = 12, SQ_BOUNCES = 15, SQ_SAMPLE = 16,
@@ -187,14 +192,14 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   // footprint) compiled in
   constexpr uint32_t FEAT = FEAT_XFORM | FEAT_MEDIUM | FEAT_RECT | (TEX ? FEAT_TEXTURE : 0u);
   extern __shared__ uint4 s_mem[];
-  constexpr uint32_t OP_SLOW_LAST = GENB ? (uint32_t)OP_BEND : (uint32_t)OP_PRISM;  // records a slow pass executes
+  constexpr uint32_t OP_SLOW_LAST = (uint32_t)OP_SEG;  // records a slow pass executes: SPHERE .. SEG (BEND only occurs in GENB programs)
   constexpr uint32_t STACK_LEVELS = GENB ? 2 * MAX_XFORM_DEPTH : MAX_XFORM_DEPTH;   // a boundary stream nests below the medium's own wrappers
   constexpr bool USE_LDS = PROG != 0;
   const uint32_t win_bytes = RSZ * window;
   if (USE_LDS) {
     for (uint32_t i = threadIdx.x; i < window; i += blockDim.x) {
       uint4 h = sc.hi[i];
-      if ((h.w & 0xffu) == OP_BOX) h.z *= RSZ;
+      if ((h.w & 0xffu) == OP_BOX || (h.w & 0xffu) == OP_SEG) h.z *= RSZ;
       if ((h.w & 0xffu) == OP_MEDIUM) h.x *= RSZ;
       s_mem[2u * i] = sc.lo[i];
       s_mem[2u * i + 1u] = h;
@@ -238,6 +243,8 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   uint32_t r_xy = 0, r_sample = 0, r_bounces = 0;  // the path's pixel (x | row << 16), sample and bounce count: its RNG stream for media
   V3 r_strength = o;                                // the path's strength rides along (lib.rs:77)
   V3 sv_o = o, sv_d = o;                            // level 0 of the transform stack (the ray outside the outermost wrapper)
+  float seg_t = F32_MAX;                             // the hoisted segment's candidate for this ray: t and record pc (| prism face), see OP_SEG
+  uint32_t seg_pc = 0;
   uint32_t bmode = 0;                                // GENB: 0 = main walk, 1 / 2 = inside a boundary stream, query 1 / 2
   float t_lo = t_near, b_saved = 0.f, b_t1 = 0.f;    // GENB: lower end of the current range; the main walk's best; query 1's t
   Counts cnt = {0, 0, 0, 0};
@@ -248,13 +255,53 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   uint32_t n_box_it = 0, n_box_lanes = 0, n_slow_it = 0, n_slow_lanes = 0, n_shade = 0, n_shade_lanes = 0, n_refill = 0;
   uint32_t n_gen = 0, n_gen_lanes = 0;
   unsigned long long t_gen = 0;
+#ifdef RT_CENSUS
+  unsigned long long census[2] = {0ull, 0ull};  // lane c < 16 holds class c of the box-step census [0] and of the slow-pass census [1]
+#endif
   unsigned long long t_shade = 0, t_serv = 0, t_box = 0, t_slow = 0, t_refill = 0, t_fin = 0, n_serv = 0, t_mark = 0, t_mark2 = 0;  // COUNT: s_memtime shares
 
+#define RT_HOIST 1       // OP_SEG commits the candidate hoist_eval found when the ray was created
 #define RT_REG_STACK0 1  // PUSH / POP of an outermost wrapper touch no memory (book-2: the moving sphere, the sphere cloud)
-#define RT_SAME_KIND_RUN 0  // (consecutive SPHERE / RECT records in one go: the lock-step kernel's; here the box lanes would wait: book2_bvh +1.7 %)
+#ifndef RT_POOL_SAME_KIND_RUN
+#define RT_POOL_SAME_KIND_RUN 0
+#endif
+#define RT_SAME_KIND_RUN RT_POOL_SAME_KIND_RUN  // (consecutive SPHERE / RECT records in one go: the lock-step kernel's; here the box lanes would wait: book2_bvh +1.7 %)
 #include "rt_full_ops.inc"
 #undef RT_SAME_KIND_RUN
 #undef RT_REG_STACK0
+#undef RT_HOIST
+  // The hoisted segment (flat_scene.h OP_SEG) for a ray that is being created: Sphere::hit / Rect::hit / rect_prism's six
+  // Rect::hit for every record of the segment in order against a shrinking t -- exactly what the walk would do with
+  // t_range.end = f32::MAX -- keeping the closest candidate.  Called by the shade and camera passes with every lane on the
+  // SAME record (the record words are wave-uniform: scalar branches, no divergence but hit / miss).
+  auto hoist_eval = [&](const V3 ro, const V3 rd, const float rtime, float& c_t, uint32_t& c_pc, uint32_t& n_tests) {
+    c_t = F32_MAX, c_pc = 0u, n_tests = 0u;
+    const uint32_t q_end = load_const(&lc->seg_end);
+    for (uint32_t q = load_const(&lc->seg_first); q < q_end; q += RSZ) {
+      const uint4 q_lo = RT_FETCH_LO(q), q_hi = RT_FETCH_HI(q);
+      const uint32_t w = __builtin_amdgcn_readfirstlane(q_hi.w), q_op = w & 0xffu;
+      float t;
+      if (q_op == OP_SPHERE) {
+        V3 lo_o = ro;
+        if (w & F_TRANSLATE) lo_o = vsub(ro, mk(u2f(q_lo.x), u2f(q_lo.y), u2f(q_lo.z)));
+        if (w & F_MOVE) {
+          const uint4 mv = RT_FETCH_LO(q + RSZ);
+          lo_o = vsub(lo_o, smul(rtime, mk(u2f(mv.x), u2f(mv.y), u2f(mv.z))));
+        }
+        if (sphere_hit_t(lo_o, rd, u2f(q_lo.w), t_near, c_t, t)) c_t = t, c_pc = q;
+        n_tests += 1u;
+        if (w & F_MOVE) q += RSZ;
+      } else if (q_op == OP_RECT) {
+        if (rect_hit_t(ro, rd, (w >> F_AXIS_SHIFT) & 3u, u2f(q_lo.x), u2f(q_lo.y), u2f(q_lo.z), u2f(q_lo.w), u2f(q_hi.x), t_near, c_t, t))
+          c_t = t, c_pc = q;
+        n_tests += 1u;
+      } else if (q_op == OP_PRISM) {
+        uint32_t face = 0;
+        if (prism_hit_t(q_lo, q_hi, ro, rd, t_near, c_t, t, face)) c_t = t, c_pc = q | face;
+        n_tests += 6u;
+      }
+    }
+  };
 
   for (;;) {
     uint32_t op = have_ray ? (cur_hi.w & 0xffu) : 0xffu;
@@ -414,6 +461,11 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         RT_TL_SHADE(take, m_live);
         if (live) {  // push onto T
           const uint32_t i = t_count + lane_rank(m_live);
+          float c_t;
+          uint32_t c_pc, c_n;
+          hoist_eval(so, sd, stime, c_t, c_pc, c_n);
+          if (COUNT) cnt.prim += c_n, trp += c_n;
+          TQ_ST_F(TQ_SEG_T, i, c_t), TQ_ST_U(TQ_SEG_PC, i, c_pc);
           TQ_ST_F(TQ_O, i, so.x), TQ_ST_F(TQ_O + 1, i, so.y), TQ_ST_F(TQ_O + 2, i, so.z);
           TQ_ST_F(TQ_D, i, sd.x), TQ_ST_F(TQ_D + 1, i, sd.y), TQ_ST_F(TQ_D + 2, i, sd.z);
           TQ_ST_F(TQ_TIME, i, stime);
@@ -519,13 +571,18 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
 #else
           const uint32_t i = t_count + lane_rank(m_live);
 #endif
+          float c_t;
+          uint32_t c_pc, c_n;
+          hoist_eval(so, sd, stime, c_t, c_pc, c_n);
+          if (COUNT) cnt.prim += c_n;
+          TQ_ST_F(TQ_SEG_T, i, c_t), TQ_ST_U(TQ_SEG_PC, i, c_pc);
           TQ_ST_F(TQ_O, i, so.x), TQ_ST_F(TQ_O + 1, i, so.y), TQ_ST_F(TQ_O + 2, i, so.z);
           TQ_ST_F(TQ_D, i, sd.x), TQ_ST_F(TQ_D + 1, i, sd.y), TQ_ST_F(TQ_D + 2, i, sd.z);
           TQ_ST_F(TQ_TIME, i, stime);
           TQ_ST_F(TQ_STRENGTH, i, 1.f), TQ_ST_F(TQ_STRENGTH + 1, i, 1.f), TQ_ST_F(TQ_STRENGTH + 2, i, 1.f);
           TQ_ST_U(TQ_BOUNCES, i, 0u), TQ_ST_U(TQ_SAMPLE, i, s);
           TQ_ST_U(TQ_XY, i, x | (row << 16));
-          if (COUNT && tr_out) TQ_ST_U(TQ_TRACE, i, rng.draws), TQ_ST_U(TQ_TRACE + 1, i, 0u), TQ_ST_U(TQ_TRACE + 2, i, 0u);
+          if (COUNT && tr_out) TQ_ST_U(TQ_TRACE, i, rng.draws), TQ_ST_U(TQ_TRACE + 1, i, 0u), TQ_ST_U(TQ_TRACE + 2, i, c_n);
           if (COUNT) cnt.rays++;
         }
 #if RT_T_PRIORITY
@@ -607,6 +664,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
             time = TQ_LD_F(TQ_TIME, i);
             r_strength = mk(TQ_LD_F(TQ_STRENGTH, i), TQ_LD_F(TQ_STRENGTH + 1, i), TQ_LD_F(TQ_STRENGTH + 2, i));
             r_xy = TQ_LD_U(TQ_XY, i), r_sample = TQ_LD_U(TQ_SAMPLE, i), r_bounces = TQ_LD_U(TQ_BOUNCES, i);
+            seg_t = TQ_LD_F(TQ_SEG_T, i), seg_pc = TQ_LD_U(TQ_SEG_PC, i);
             if (COUNT && tr_out) tr_d = TQ_LD_U(TQ_TRACE, i), tr_a = TQ_LD_U(TQ_TRACE + 1, i), tr_p = TQ_LD_U(TQ_TRACE + 2, i);
             pc = 0, best = F32_MAX, hmat = NO_HIT, ev_draws = 0;
             depth = 0, tag = 0, nhits = 0, root_hits = 0;
@@ -647,7 +705,9 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
 #define RT_R_PIXEL ((load_const(&lc->P.ny) - 1u - (r_xy >> 16)) * load_const(&lc->P.nx) + (r_xy & 0xffffu))
 #define RT_R_EVENT (r_bounces + 1u)
 #define RT_PHASE_PRIO 1  // (the pool schedule sets wave priorities per phase: see RT_FULL_SLOW_PRIO)
+#define RT_CENSUS_HERE 1
 #include "rt_full_traverse.inc"
+#undef RT_CENSUS_HERE
 #undef RT_PHASE_PRIO
 #undef RT_R_PIXEL
 #undef RT_R_EVENT
@@ -672,6 +732,11 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
       atomicAdd(&sched[15], t_refill);
       atomicAdd(&sched[12], (unsigned long long)n_gen), atomicAdd(&sched[13], (unsigned long long)n_gen_lanes), atomicAdd(&sched[14], t_gen);
       atomicAdd(&counters[6], t_fin), atomicAdd(&counters[5], n_serv);
+#ifdef RT_CENSUS
+    }
+    if (lane < 16u) atomicAdd(&counters[32u + lane], census[0]), atomicAdd(&counters[48u + lane], census[1]);
+    if (lane == 0) {
+#endif
       atomicAdd(&counters[16], t_shade), atomicAdd(&counters[17], t_serv - t_shade), atomicAdd(&counters[18], t_box),
           atomicAdd(&counters[19], t_slow);
       // wave timeline (rt_pool.h)

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
                                                         float* __restrict__ g_stack, uint32_t window) {
   constexpr uint32_t FEAT = FEAT_XFORM | FEAT_MEDIUM | FEAT_RECT | (TEX ? FEAT_TEXTURE : 0u);
   extern __shared__ uint4 s_mem[];
-  constexpr uint32_t OP_SLOW_LAST = GENB ? (uint32_t)OP_BEND : (uint32_t)OP_PRISM;
+  constexpr uint32_t OP_SLOW_LAST = (uint32_t)OP_SEG;  // SPHERE .. SEG (this kernel steps over OP_SEG: it hoists nothing)
   constexpr uint32_t STACK_LEVELS = GENB ? 2 * MAX_XFORM_DEPTH : MAX_XFORM_DEPTH;
   constexpr bool USE_LDS = PROG != 0;
   const uint32_t win_bytes = RSZ * window;
@@ -57,6 +57,8 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   uint32_t depth = 0, tag = 0, nhits = 0, root_hits = 0, ev_draws = 0;
   V3 sv_o = mk(0.f, 0.f, 0.f), sv_d = sv_o;  // level 0 of the transform stack (rt_full_ops.inc)
   uint32_t r_pixel = 0, r_sample = 0, r_event = 0;
+  float seg_t = F32_MAX;  // (OP_SEG of rt_full_ops.inc: compiled out here, RT_HOIST = 0)
+  uint32_t seg_pc = 0;
   uint32_t bmode = 0;
   float t_lo = t_near, b_saved = 0.f, b_t1 = 0.f;
   Counts cnt = {0, 0, 0, 0};
@@ -67,11 +69,13 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   uint32_t n_box_it = 0, n_box_lanes = 0, n_slow_it = 0, n_slow_lanes = 0, n_shade = 0, n_shade_lanes = 0, n_refill = 0;
   unsigned long long t_shade = 0, t_box = 0, t_slow = 0, t_mark = 0;
 
+#define RT_HOIST 0
 #define RT_REG_STACK0 0  // measured: six more live registers cost this kernel 7 % on sphere lists, Cornell's wrappers gain nothing
 #define RT_SAME_KIND_RUN 1  // consecutive SPHERE / RECT records in one go: simple_light (200 spheres) 16.0 -> 9.4 ms, Cornell 3.7 -> 3.6, smoke boxes 7.5 -> 7.15
 #include "rt_full_ops.inc"
 #undef RT_SAME_KIND_RUN
 #undef RT_REG_STACK0
+#undef RT_HOIST
 
   for (;;) {
     // ============================== SHADE / GEN (every lane, its own path) ==========================

@@ -110,6 +110,8 @@ struct rtg_scene {
   int wg_per_cu = 0;                       // 0 = ask the occupancy API
   int full_threads = 0;                    // full-feature pool kernel: 0 = the variant's maximum (RTG_BLOCK overrides)
   int pool_threads = 0;                    // lean ray-pool kernel: 0 = ONE 16-wave workgroup per CU shares one LDS copy of the program (RTG_BLOCK overrides)
+  int hoist = 1;                            // full-feature pool kernel: evaluate the hoisted segment when a ray is created (flat_scene.h OP_SEG); 0 = the walk executes its records
+  uint32_t seg_first = 0, seg_end = 0;      // ... its records, as record indices (0, 0: the program has none)
   int drain_share = 1;                      // pool kernels, drain-phase work sharing (rt_pool_full.h RT_DRAIN_SHARE): 0 = off
   int small_frames = 1;                    // rtg_launch.inc pool_geometry: frames smaller than the chip get small workgroups and reservations
   LaunchCtx ctx[RTG_MAX_FRAMES];           // frames in flight
@@ -135,7 +137,7 @@ static int ctx_acquire(rtg_scene* s) {
   LaunchCtx* c = &s->ctx[s->next_ctx];
   s->next_ctx = (s->next_ctx + 1) % s->n_ctx;
   if (!c->d_counters) {
-    if (hipMalloc((void**)&c->d_counters, 32 * sizeof(unsigned long long)) != hipSuccess || hipMemset(c->d_counters, 0, 32 * sizeof(unsigned long long)) != hipSuccess ||
+    if (hipMalloc((void**)&c->d_counters, 64 * sizeof(unsigned long long)) != hipSuccess || hipMemset(c->d_counters, 0, 64 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void**)&c->d_consts, sizeof(LaunchConsts)) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
         hipEventCreate(&c->ev1) != hipSuccess || hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess)
       return fail(RTG_ERR_DEVICE, "scene: launch-context allocation failed");
@@ -472,6 +474,8 @@ int rtg_scene_create(rtg_builder* b, const rtg_id* world, size_t n, int device, 
   s->dev.n_prog = s->n_prog;
   s->dev.n_mat = s->n_mat;
   for (const Packet& h : fs.hi) s->n_box += (h.w[3] & 0xffu) == OP_BOX ? 1u : 0u;
+  for (size_t i = 0; i < fs.hi.size(); i++)
+    if ((fs.hi[i].w[3] & 0xffu) == OP_SEG) s->seg_first = (uint32_t)i + 1u, s->seg_end = fs.hi[i].w[2];
   if ((fs.features & (FEAT_ALL | FEAT_BOUNDARY)) == 0) {  // lean program (BOX / SPHERE / END): layout of its LDS image (rt_pool.h)
     std::vector<uint32_t> ops(fs.hi.size()), off(fs.hi.size());
     for (size_t i = 0; i < fs.hi.size(); i++) ops[i] = fs.hi[i].w[3];
@@ -538,6 +542,7 @@ int rtg_scene_set_option(rtg_scene* s, const char* name, int value) {
   }
   else if (k == "wg_per_cu") s->wg_per_cu = value;
   else if (k == "drain_share") s->drain_share = value;
+  else if (k == "hoist") s->hoist = value;
   else if (k == "small_frames") s->small_frames = value;        // 0: one geometry for every frame size (measurement switch)
   else if (k == "verbose") s->verbose = value;                  // print launch geometry / schedule statistics to stderr
   else if (k == "window") s->window = value;                    // full-feature kernel: records staged in LDS, -1 = automatic
@@ -635,6 +640,7 @@ int rtg_par_cast_device(rtg_scene* s, const rtg_camera* camera, const rtg_params
   if (count) {
     HIP_TRY_CTX(hipMemsetAsync(s->cx->d_counters, 0, 7 * sizeof(unsigned long long), stream));
     HIP_TRY_CTX(hipMemsetAsync(s->cx->d_counters + 8, 0, 24 * sizeof(unsigned long long), stream));
+    HIP_TRY_CTX(hipMemsetAsync(s->cx->d_counters + 32, 0, 32 * sizeof(unsigned long long), stream));  // (RT_CENSUS builds)
   }
 #ifdef RT_TIMELINE  // diagnostic build (rt_pool.h RT_TL_*): one 16-dword drain record per wave, dumped to $RTG_TIMELINE_OUT
   static uint32_t* d_tl = nullptr;
@@ -702,6 +708,20 @@ int rtg_par_cast_device(rtg_scene* s, const rtg_camera* camera, const rtg_params
         fprintf(stderr, "[rtg] services %llu: finish step %.1f%% of wave time (%.0f ticks each), refill step %.1f%% (%.0f ticks per refill)\n", f[0],
                 100 * f[1] / tt, f[0] ? (double)f[1] / f[0] : 0., 100 * q[15] / tt, q[6] ? (double)q[15] / q[6] : 0.);
       }
+#ifdef RT_CENSUS
+      {
+        unsigned long long c[32];
+        HIP_TRY(hipMemcpy(c, s->cx->d_counters + 32, sizeof(c), hipMemcpyDeviceToHost));
+        static const char* nm[13] = {"BOX", "END", "no-ray", "held", "?", "?", "SPHERE", "RECT", "PUSH", "POP", "MEDIUM", "PRISM", "BEND"};
+        for (int k = 0; k < 2; k++) {
+          std::string line;
+          char buf[64];
+          for (int j = 0; j < 13; j++)
+            if (c[16 * k + j]) snprintf(buf, sizeof buf, " %s %.1f", nm[j], (double)c[16 * k + j] / (double)c[16 * k + 15]), line += buf;
+          fprintf(stderr, "[rtg] lane census at %s (%llu):%s\n", k ? "slow-pass iterations" : "box steps", c[16 * k + 15], line.c_str());
+        }
+      }
+#endif
       fprintf(stderr, "[rtg] pool schedule: box steps %llu (avg %.1f lanes), sphere passes %llu (avg %.1f lanes), shade passes %llu "
                 "(avg %.1f lanes), end / camera-ray passes %llu (avg %.1f lanes), refills %llu (avg %.1f lanes)\n", q[0], q[0] ? (double)q[1] / q[0] : 0.0, q[2],
                 q[2] ? (double)q[3] / q[2] : 0.0, q[4], q[4] ? (double)q[5] / q[4] : 0.0, q[12], q[12] ? (double)q[13] / q[12] : 0.0, q[6],

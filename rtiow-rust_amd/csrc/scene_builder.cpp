@@ -454,21 +454,57 @@ void SceneBuilder::emit(uint32_t id, bool under_bvh, int depth, FlatScene* out, 
   push(out, w->f[0], w->f[1], w->f[2], pre[0], fbits(pre[1]), fbits(pre[2]), (uint32_t)at, OP_POP | (kind << F_KIND_SHIFT) | pre_flag);
 }
 
+// Is world object `id` ONE plain primitive record -- a (fused) SPHERE, a RECT or a rect_prism?
+static bool is_plain_primitive(const SceneBuilder& b, uint32_t id) {
+  if (fuse_primitive(b, id, nullptr, false, true)) return true;
+  float p0[3], p1[3];
+  uint32_t mat;
+  return match_prism(b, id, p0, p1, &mat);
+}
+
 void SceneBuilder::flatten(const uint32_t* world, size_t n, FlatScene* out) const {
+  for (size_t i = 0; i < n; i++)
+    if (world[i] >= objects.size()) throw BuildError{-1, "scene: bad world object handle"};
+  // The hoisted segment (flat_scene.h OP_SEG): the longest run of >= 2 consecutive top-level plain primitives.  Only programs
+  // the full-feature POOL kernel renders get one (a Bvh somewhere, not a lean BOX / SPHERE program, no FEAT_DEEP shape): the
+  // first flattening finds that out, the second one emits the record.
+  size_t seg0 = 0, seg1 = 0;
+  for (size_t i = 0; i < n;) {
+    size_t j = i;
+    while (j < n && is_plain_primitive(*this, world[j])) j++;
+    if (j - i >= 2 && j - i > seg1 - seg0) seg0 = i, seg1 = j;
+    i = j > i ? j : i + 1;
+  }
+  flatten_program(world, n, out, 0, 0);
+  bool has_box = false;
+  for (const Packet& h : out->hi) has_box |= (h.w[3] & 0xffu) == OP_BOX;
+  const bool full_pool = has_box && (out->features & (FEAT_XFORM | FEAT_MEDIUM | FEAT_RECT | FEAT_TEXTURE | FEAT_BOUNDARY)) != 0u &&
+                         !(out->features & FEAT_DEEP);
+  if (hoist_segments && full_pool && seg1 > seg0) flatten_program(world, n, out, seg0, seg1);
+  finish_materials(out);
+}
+
+// world objects [seg0, seg1) (seg1 > seg0) are preceded by an OP_SEG record that skips them
+void SceneBuilder::flatten_program(const uint32_t* world, size_t n, FlatScene* out, size_t seg0, size_t seg1) const {
   out->lo.clear(), out->hi.clear(), out->mat.clear(), out->tex.clear();
   out->features = 0;
   // Runs of consecutive list-level objects that hold no Bvh are straight-line code every ray executes in
-  // the same order: their first record is marked F_GATHER so a scheduler can batch the rays there.
-  size_t run_start = 0;
+  // the same order: their first record is marked F_GATHER so a scheduler can batch the rays there.  (The records of a hoisted
+  // segment do not count: a kernel that commits the segment at its OP_SEG record never executes them.)
+  size_t run_start = 0, run_skipped = 0;
   bool in_run = false;
   auto close_run = [&](size_t end) {
-    if (in_run && end - run_start >= 4) out->hi[run_start].w[3] |= F_GATHER;
-    in_run = false;
+    if (in_run && end - run_start - run_skipped >= 4) out->hi[run_start].w[3] |= F_GATHER;
+    in_run = false, run_skipped = 0;
   };
+  size_t seg_at = 0;
   for (size_t i = 0; i < n; i++) {
-    if (world[i] >= objects.size()) throw BuildError{-1, "scene: bad world object handle"};
     const size_t at = out->lo.size();
+    if (seg1 > seg0 && i == seg0) seg_at = at, push(out, 0, 0, 0, 0, 0, 0, 0, OP_SEG);
+    const size_t first = out->lo.size();
     emit(world[i], false, 0, out);
+    if (seg1 > seg0 && i >= seg0 && i < seg1) run_skipped += out->lo.size() - first;
+    if (seg1 > seg0 && i + 1 == seg1) out->hi[seg_at].w[2] = (uint32_t)out->lo.size();
     bool has_box = false;
     for (size_t r = at; r < out->lo.size(); r++) has_box |= (out->hi[r].w[3] & 0xffu) == OP_BOX;
     if (has_box) {
@@ -479,6 +515,9 @@ void SceneBuilder::flatten(const uint32_t* world, size_t n, FlatScene* out) cons
   }
   close_run(out->lo.size());
   push(out, 0, 0, 0, 0, 0, 0, 0, OP_END);
+}
+
+void SceneBuilder::finish_materials(FlatScene* out) const {
   // Albedo range of every scattering material -- decides whether the pool kernels' "accum is +0" argument holds
   // (rt_pool.h PoolField): walks the WHOLE texture tree (a checker's children, recursively; texture.rs:12-21), any
   // reachable Perlin texture is "bright" (turb <= 2 sqrt(3) x the longest table vector, perlin.rs:31-75), and a Perlin

@@ -71,6 +71,7 @@ class SceneBuilder {
   uint32_t add_bvh(const uint32_t* objs, size_t n, float e0, float e1, bool sah = false);
   Box3 bounding_box(uint32_t obj, float e0, float e1) const;
   void flatten(const uint32_t* world, size_t n, FlatScene* out) const;
+  bool hoist_segments = true;  // flatten() may put an OP_SEG record in front of a list world's longest run of plain primitives
 
  private:
   int32_t build_bvh(std::vector<uint32_t> objs, float e0, float e1);
@@ -80,6 +81,8 @@ class SceneBuilder {
   void emit(uint32_t obj, bool under_bvh, int depth, FlatScene* out, int boundary = 0, bool mark_roots = true, int saves = 0) const;
   void emit_bvh(int32_t node, int depth, FlatScene* out, int boundary, bool mark_roots, int saves) const;
   bool holds_medium(uint32_t obj) const;
+  void flatten_program(const uint32_t* world, size_t n, FlatScene* out, size_t seg0, size_t seg1) const;
+  void finish_materials(FlatScene* out) const;
 };
 
 struct BuildError {

@@ -11,6 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 OP_END, OP_BOX, OP_SPHERE, OP_RECT, OP_PUSH, OP_POP, OP_MEDIUM, OP_PRISM = range(8)
+OP_SEG, OP_EXT = 9, 12   # flat_scene.h
 
 
 def header_symbols():
@@ -137,7 +138,7 @@ def test_flat_program_of_cornell_and_book2(pkg):
     assert int((ops == OP_PUSH).sum()) == 1               # Translate{RotateY{Bvh}}: one wrapper level
     # Translate{LinearMove{Sphere}} (main.rs:218-229) is ONE fused SPHERE record (F_TRANSLATE | F_MOVE) + its motion vector
     mv = np.nonzero((ops == OP_SPHERE) & ((words[:, 7] >> 20) & 1 == 1))[0]
-    assert len(mv) == 1 and ops[mv[0] + 1] == 11 and words[mv[0], 7] & (1 << 8)
+    assert len(mv) == 1 and ops[mv[0] + 1] == OP_EXT and words[mv[0], 7] & (1 << 8)
     assert words[mv[0], :4].view(np.float32).tolist() == [400.0, 400.0, 200.0, 50.0]
     assert words[mv[0] + 1, :3].view(np.float32).tolist() == [30.0, 0.0, 0.0]
     # ... only in the order the reference applies them: LinearMove{Translate{Sphere}} keeps its wrapper (around a fused Translate)
@@ -146,7 +147,7 @@ def test_flat_program_of_cornell_and_book2(pkg):
     w2, _ = b2.flatten([b2.linear_move(b2.translate(pkg.scenes.v(1, 2, 3), b2.sphere(1.0, m)), pkg.scenes.v(1, 0, 0))])
     assert (w2[:, 7] & 0xff).tolist() == [OP_PUSH, OP_SPHERE, OP_POP, OP_END] and not (w2[1, 7] >> 20) & 1
     w3, _ = b2.flatten([b2.flip_normals(b2.linear_move(b2.sphere(1.0, m), pkg.scenes.v(0, 1, 0)))])
-    assert (w3[:, 7] & 0xff).tolist() == [OP_SPHERE, 11, OP_END] and (w3[0, 7] >> 20) & 1 and (w3[0, 7] >> 9) & 1 and not w3[0, 7] & (1 << 8)
+    assert (w3[:, 7] & 0xff).tolist() == [OP_SPHERE, OP_EXT, OP_END] and (w3[0, 7] >> 20) & 1 and (w3[0, 7] >> 9) & 1 and not w3[0, 7] & (1 << 8)
     assert int((ops == OP_BOX).sum()) == (2 * 400 - 1) + (2 * 1000 - 1)
     med = np.nonzero(ops == OP_MEDIUM)[0]
     assert (ops[med + 1] == OP_SPHERE).all()            # boundary record follows its medium
@@ -208,7 +209,7 @@ def test_reference_error_behaviour(pkg):
     # Every graph the reference's types allow flattens.  Shapes the scheduled kernels do not walk (a medium inside a medium's
     # boundary, a medium below an And below a Bvh, more than 4 nested wrappers) set FEAT_DEEP (128): the general walk of the
     # baseline kernel renders them.  RTG_ERR_UNSUPPORTED is left for nesting beyond that walk's (documented) stack bounds.
-    FEAT_BOUNDARY, FEAT_DEEP, OP_BEND, OP_SAVE, OP_MERGE = 16, 128, 8, 9, 10
+    FEAT_BOUNDARY, FEAT_DEEP, OP_BEND, OP_SAVE, OP_MERGE = 16, 128, 8, 10, 11
     iso = b.isotropic(b.constant(S.vfrom(1.0)))
     box = b.rect_prism(S.v(0, 0, 0), S.v(1, 1, 1), m)
     words, feat = b.flatten([b.constant_medium(box, 0.1, iso)])   # a boundary may be any object graph ...

@@ -94,12 +94,13 @@ def test_fuzz_deep_shapes_flatten_on_host(pkg, seed):
     b, world, _ = _build(pkg, pkg.load(), 9000 + seed, 24, 16, general_boundaries=True, deep_shapes=True)
     words, feat = b.flatten(world)
     ops = words[:, 7] & 0xff
-    assert int((ops == 9).sum()) == int((ops == 10).sum())
+    OP_SAVE, OP_MERGE = 10, 11   # flat_scene.h
+    assert int((ops == OP_SAVE).sum()) == int((ops == OP_MERGE).sum())
     level = 0
     for o in ops:
-        level += 1 if o == 9 else -1 if o == 10 else 0
+        level += 1 if o == OP_SAVE else -1 if o == OP_MERGE else 0
         assert 0 <= level <= 4
-    if (ops == 9).any():
+    if (ops == OP_SAVE).any():
         assert feat & 128
     depth = max_depth = 0
     for o in ops:
@@ -107,7 +108,7 @@ def test_fuzz_deep_shapes_flatten_on_host(pkg, seed):
         max_depth = max(max_depth, depth)
     med = np.nonzero(ops == 6)[0]
     nested = any(np.isin(ops[m + 1:int(words[m, 4])], (6,)).any() for m in med)
-    assert bool(feat & 128) == bool((ops == 9).any() or nested or _deep_wrappers(words)), (seed, feat)
+    assert bool(feat & 128) == bool((ops == OP_SAVE).any() or nested or _deep_wrappers(words)), (seed, feat)
 
 
 def _deep_wrappers(words):
@@ -140,7 +141,7 @@ def test_fuzz_deep_shapes_cover_all_three(pkg):
         b, world, _ = _build(pkg, pkg.load(), 9000 + seed, 24, 16, general_boundaries=True, deep_shapes=True)
         words, feat = b.flatten(world)
         ops = words[:, 7] & 0xff
-        if (ops == 9).any():
+        if (ops == 10).any():   # OP_SAVE (flat_scene.h)
             seen.add("medium below And below Bvh")
         if any(np.isin(ops[m + 1:int(words[m, 4])], (6,)).any() for m in np.nonzero(ops == 6)[0]):
             seen.add("medium inside a boundary")

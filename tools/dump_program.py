@@ -12,7 +12,7 @@ fn, nx, ny, ns = scene_cases.CASES[name]
 b = be.builder()
 world, cam, _ = fn(pkg, b, nx, ny)
 words, feat = b.flatten(world)
-OPS = ["END", "BOX", "SPHERE", "RECT", "PUSH", "POP", "MEDIUM", "PRISM", "BEND", "SAVE", "MERGE", "EXT"]
+OPS = ["END", "BOX", "SPHERE", "RECT", "PUSH", "POP", "MEDIUM", "PRISM", "BEND", "SEG", "SAVE", "MERGE", "EXT"]
 ops = words[:, 7] & 0xff
 print("%s: %d records, features 0x%x" % (name, len(words), feat), dict(collections.Counter(OPS[o] for o in ops)))
 pc, depth = 0, 0
@@ -23,6 +23,8 @@ while pc < len(words):  # walk the list level: skip over Bvh subtrees
         extra = "skip -> %d (subtree of %d records)" % (w[6], w[6] - pc - 1)
     if op == 6:
         extra = "end -> %d" % w[4]
+    if op == 9:
+        extra = "hoisted segment: records %d .. %d" % (pc + 1, w[6] - 1)
     print("%5d %-7s flags %06x %s %s" % (pc, OPS[op], fl, "GATHER" if (int(w[7]) & (1 << 15)) else "", extra))
     if op == 0:
         break

@@ -5,6 +5,7 @@ The reference holds no golden vectors for this path and cannot be compiled here 
 the fixtures pin the oracle's own outputs: they catch accidental changes of the restatement and any
 host/compiler dependence, and the GPU tests compare the HIP path against the same files.
 Run from the repo root:  python tools/gen_golden.py
+                         python tools/gen_golden.py --configs [C1 C2 ...]   (tests/golden/config_hashes.json, below)
 """
 import json
 import os
@@ -56,5 +57,75 @@ def main():
     print("wrote fixtures:", {f: os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD)})
 
 
+# ---- BASELINE.json's five configs at their NAMED sizes: SHA-256 of every 16-row band of the oracle's full frame ----------------
+# (C4 / C5 met the oracle on 6 % of their pixels.)  The frames themselves are 4-12 MB each and take the oracle
+# minutes on all cores, so the fixture holds hashes: data, no reference text, nothing read from /root/reference at test time.
+CONFIGS = {
+    # key: (scene case, nx, ny, ns, BASELINE.json configs[] index)
+    "C1_cornell_300x300x100": ("cornell", 300, 300, 100, 0),
+    "C2_book1_1200x800x50": ("book1", 1200, 800, 50, 1),
+    "C3_book1_1200x800x500": ("book1", 1200, 800, 500, 2),
+    "C4_book2_800x800x1000": ("book2", 800, 800, 1000, 3),
+    "C4_book2_bvh_800x800x1000": ("book2_bvh", 800, 800, 1000, 3),
+    "C5_book2_800x800x5000": ("book2", 800, 800, 5000, 4),
+}
+BAND_ROWS = 16
+
+
+def canonical_bytes(a):
+    """float32 bytes with every NaN replaced by ONE quiet NaN (x86 and gfx950 differ in NaN sign / payload;
+    conftest.assert_bit_equal treats NaN == NaN the same way)."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).copy()
+    u[np.isnan(u.view(np.float32))] = 0x7FC00000
+    return u.tobytes()
+
+
+def owned_mask(nx, ny, rank, nranks, tile):
+    tx = (np.arange(nx) // tile)[None, :]
+    ty = (np.arange(ny) // tile)[:, None]
+    return ((ty * ((nx + tile - 1) // tile) + tx) % nranks) == rank
+
+
+def frame_hashes(frame):
+    """What tests/test_configs_gpu.py recomputes from the GPU's frame: one digest per 16-row band (row 0 = top), one per
+    shard of the 8-rank interleaves bench.py / rtg_par_cast_multi use (16x16 and 8x8 tiles: the shard's pixels in row-major
+    order), and one over the whole frame."""
+    import hashlib
+    ny, nx, _ = frame.shape
+    h = {"bands": [hashlib.sha256(canonical_bytes(frame[r:r + BAND_ROWS])).hexdigest() for r in range(0, ny, BAND_ROWS)],
+         "frame": hashlib.sha256(canonical_bytes(frame)).hexdigest(), "mean": float(frame.astype(np.float64).mean())}
+    for tile in (16, 8):
+        h["shards_of_8_tile%d" % tile] = [
+            hashlib.sha256(canonical_bytes(frame[owned_mask(nx, ny, r, 8, tile)])).hexdigest() for r in range(8)]
+    return h
+
+
+def configs(which):
+    import time
+    pkg = graft.load_package()
+    ora = graft.load_oracle()
+    path = os.path.join(GOLD, "config_hashes.json")
+    doc = json.load(open(path)) if os.path.exists(path) else {}
+    doc["_about"] = ("SHA-256 of the CPU oracle's frames at BASELINE.json's config sizes (tools/gen_golden.py --configs): per "
+                     "16-row band, per shard of the 8-rank tile interleaves, whole frame.  float32 little-endian bytes, row 0 = "
+                     "top, NaNs canonicalised to 0x7fc00000.  seed 0xDEADBEEF, bounce cap 50.")
+    for key, (case, nx, ny, ns, idx) in CONFIGS.items():
+        if which and not any(key.startswith(w) for w in which):
+            continue
+        scene, cam, _, _, _ = build_case(pkg, ora, case, nx, ny)
+        t = time.time()
+        frame, st = scene.par_cast(cam, nx, ny, ns, stats=True)
+        entry = frame_hashes(frame)
+        entry.update(case=case, nx=nx, ny=ny, ns=ns, baseline_config=idx, oracle_seconds=round(time.time() - t, 1),
+                     counters={k: int(st[k]) for k in ("samples", "aabb_tests", "prim_tests", "shaded_hits", "rays", "draws")})
+        doc[key] = entry
+        with open(path, "w") as f:     # after every config: C5 alone is ~15 minutes of all cores
+            json.dump(doc, f, indent=1, sort_keys=True)
+        print(key, "%.0f s" % (time.time() - t), entry["frame"][:16], entry["counters"], flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--configs":
+        configs(sys.argv[2:])
+    else:
+        main()
