@@ -13,7 +13,16 @@ oracle, bit for bit.
 
 Sharding is by 16x16 pixel tiles, tile_index % nranks == rank (rtg_params; bench.py --gpus N uses exactly this), so
 "rank r of 64" is a subset of "rank r of 8": the oracle checks full-spp pixels without rendering 400 M samples per case.
+
+EVERY pixel of every config is pinned besides: tests/golden/config_hashes.json holds the SHA-256 of each 16-row band of the
+oracle's full frame at the named size and sample count, of the whole frame, and of each shard of the two 8-rank tile
+interleaves (tools/gen_golden.py --configs: the oracle on all cores of the build container, C5 alone 37 minutes); the tests
+below hash what the GPU renders and compare (test_config_every_pixel_*).
 """
+import hashlib
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -128,3 +137,63 @@ def test_config_c5_book2_800x800x5000_rank_of_8(pkg, gpu, oracle, rank):
         m = _owned_mask(nx, ny, sub, 64)
         assert (m & ~mask).sum() == 0
         assert_bit_equal(part[m], ref[m], "C5 rank %d of 8, tiles %% 64 == %d" % (rank, sub))
+
+
+# ---- every pixel of every config against the oracle's committed digests -------------------------------------------------------
+_HASHES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config_hashes.json")
+BAND_ROWS = 16
+
+
+def _canonical_bytes(a):
+    """as tools/gen_golden.py canonical_bytes: float32 bytes, every NaN as ONE quiet NaN"""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).copy()
+    u[np.isnan(u.view(np.float32))] = 0x7FC00000
+    return u.tobytes()
+
+
+def _sha(a):
+    return hashlib.sha256(_canonical_bytes(a)).hexdigest()
+
+
+def _config(key):
+    with open(_HASHES) as f:
+        doc = json.load(f)
+    assert key in doc, "tests/golden/config_hashes.json lacks %s (tools/gen_golden.py --configs)" % key
+    return doc[key]
+
+
+@pytest.mark.parametrize("key", ["C1_cornell_300x300x100", "C2_book1_1200x800x50", "C3_book1_1200x800x500", "C4_book2_800x800x1000",
+                                 "C4_book2_bvh_800x800x1000", "C5_book2_800x800x5000"])
+def test_config_every_pixel_against_the_oracle_digests(pkg, gpu, key):
+    """The WHOLE frame of each of BASELINE.json's configs at its named size: every 16-row band's SHA-256 equals the digest of the
+    oracle's band (100 % of the pixels, where the direct comparisons above sample C4 / C5), and the instrumented launch's
+    counters equal the oracle's."""
+    ref = _config(key)
+    nx, ny, ns = ref["nx"], ref["ny"], ref["ns"]
+    sg, cam, _, _, _ = build_case(pkg, gpu, ref["case"], nx, ny)
+    frame = sg.par_cast(cam, nx, ny, ns)
+    bands = [_sha(frame[r:r + BAND_ROWS]) for r in range(0, ny, BAND_ROWS)]
+    wrong = [i for i, (a, b) in enumerate(zip(bands, ref["bands"])) if a != b]
+    assert len(bands) == len(ref["bands"]) and not wrong, "%s: bands %s of %d differ from the oracle's" % (key, wrong, len(bands))
+    assert _sha(frame) == ref["frame"]
+    if ns <= 1000:   # (the counting variant of C5 would add seconds for nothing new: C4 is the same scene)
+        _, st = sg.par_cast(cam, nx, ny, ns, stats=True)
+        for k, v in ref["counters"].items():
+            assert st[k] == v, (key, k, st[k], v)
+
+
+@pytest.mark.parametrize("key", ["C3_book1_1200x800x500", "C5_book2_800x800x5000"])
+@pytest.mark.parametrize("tile", [16, 8])
+def test_config_every_shard_against_the_oracle_digests(pkg, gpu, key, tile):
+    """configs[2] / configs[4]: each of the 8 shards `bench.py --gpus 8` (8x8 tiles) and the 16x16 interleave render -- rank r's
+    pixels in row-major order -- against the digest of the same pixels of the oracle's frame; pixels of other ranks untouched."""
+    ref = _config(key)
+    nx, ny, ns = ref["nx"], ref["ny"], ref["ns"]
+    sg, cam, _, _, _ = build_case(pkg, gpu, ref["case"], nx, ny)
+    for rank in range(8):
+        part = sg.par_cast(cam, nx, ny, ns, rank=rank, nranks=8, tile_w=tile, tile_h=tile)
+        tx = (np.arange(nx) // tile)[None, :]
+        ty = (np.arange(ny) // tile)[:, None]
+        mask = ((ty * ((nx + tile - 1) // tile) + tx) % 8) == rank
+        assert _sha(part[mask]) == ref["shards_of_8_tile%d" % tile][rank], (key, tile, rank)
+        assert (part[~mask] == 0).all()
