@@ -203,11 +203,23 @@ def main():
     fb = frame.fb
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+    reduce_ms = []   # N > 1: what the ONE collective of a frame takes on this rank (events around it on the current stream)
+
     def step(flags=0):
         def render_shard(fb_, rank_, world_):
             p = pkg.make_params(nx, ny, spp, seed=args.seed, rank=rank_, nranks=world_, flags=flags, tile_w=frame.tile[0], tile_h=frame.tile[1])
             return scene.par_cast_device(cam, p, ctypes.c_void_p(fb_.data_ptr()), stream, want_stats=True)
-        return frame.render(render_shard)   # zero, this rank's tiles, ONE reduce(sum) to rank 0
+        if world == 1:
+            return frame.render(render_shard)
+        # the same three steps as ShardedFrame.render (zero, this rank's tiles, ONE reduce(sum) to rank 0), with events round the reduce
+        frame.fb.zero_()
+        out = render_shard(frame.fb, frame.rank, frame.world)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        frame.reduce(0)
+        e1.record()
+        reduce_ms.append((e0, e1))
+        return out
 
     # counting pass (untimed): the instrumented kernel gives N/P/H for the algorithmic byte model
     cst = step(flags=pkg.capi.FLAG_COUNTERS)
@@ -239,10 +251,21 @@ def main():
         kernel_ms.append(step()["kernel_ms"])
     sync()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # what every rank did, so that a scaling loss can be attributed: its render kernel (HIP events inside the library), its
+        # samples, and the reduce as it saw it (a rank that finishes rendering early waits for the slowest one inside the reduce)
+        timed = reduce_ms[-args.steps:]
+        mine = torch.tensor([sum(kernel_ms) / len(kernel_ms), float(px_rank * spp), sum(a.elapsed_time(b) for a, b in timed) / max(1, len(timed))],
+                            dtype=torch.float64, device=dev)
+        if backend != "nccl":
+            mine = mine.cpu()
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "kernel_ms_avg": float(v[0]), "samples": int(v[1]), "reduce_ms_avg": float(v[2])} for r, v in enumerate(allr)]
 
     # Secondary anchors of the default N = 1 run, timed in this process AFTER the headline loop (they cannot disturb it):
     # the frame north_star's target names (C3's 1200x800x500, here on ONE GPU: what `--gpus 2/4/8` is compared against) and
@@ -251,8 +274,12 @@ def main():
     default_run = (world == 1 and args.workload == "book1" and not args.bvh4 and args.bvh == "reference" and not args.spp
                    and (nx, ny) == (wnx, wny))
     if default_run and not args.no_also:
-        def anchor(wl, a_spp, a_steps):
+        from rtiow_rust_amd import roofline as rl_a
+
+        def anchor(wl, a_spp, a_steps, profile_key=None, bvh="reference"):
             a_build, anx, any_, _, _, _ = WORKLOADS[wl]
+            if bvh == "sah":
+                a_build = lambda pkg, b, nx, ny: pkg.scenes.random_scene(b, nx, ny, use_bvh="sah")  # noqa: E731
             ab = gpu.builder()
             a_objs, a_cam, _ = a_build(pkg, ab, anx, any_)
             a_scene = ab.scene(a_objs, device=dev_index)
@@ -265,10 +292,30 @@ def main():
             k_ms = [one()["kernel_ms"] for _ in range(a_steps)]
             torch.cuda.synchronize()
             a_dt = (time.perf_counter() - a_t0) / a_steps
-            return {"value": anx * any_ * a_spp / a_dt / 1e6, "unit": "Msamples/s", "ms_per_step": a_dt * 1e3,
-                    "kernel_ms_avg": sum(k_ms) / len(k_ms), "steps": a_steps, "warmup": 1}
-        also = {"book1_random_spheres_1200x800x500spp": dict(anchor("book1", 500, 5), baseline_config="configs[2] on ONE GPU (north_star target frame)"),
-                "book2_final_scene_800x800x1000spp": dict(anchor("book2", 1000, 3), baseline_config="configs[3]")}
+            res = {"value": anx * any_ * a_spp / a_dt / 1e6, "unit": "Msamples/s", "ms_per_step": a_dt * 1e3,
+                   "kernel_ms_avg": sum(k_ms) / len(k_ms), "steps": a_steps, "warmup": 1}
+            if profile_key:
+                # the same object as the headline's, from the counters collected AT this config (profiles/current.json
+                # "<workload>@<spp>"), under the same staleness rule: another build -> frac null + the reason
+                a_pmc, a_path = rl_a.find_profile(ROOT, profile_key, a_spp, frame=(anx, any_))
+                if a_pmc is not None:
+                    a_stale = rl_a.profile_staleness(a_pmc, ROOT, lib_override=os.environ.get("RTIOW_GPU_LIB"),
+                                                     knobs=rl_a.knob_differences(a_pmc, os.environ))
+                    r = rl_a.valu_roofline(a_pmc, sum(k_ms) / len(k_ms) * 1e-3, samples=anx * any_ * a_spp, stale=a_stale)
+                    res["roofline"] = {"bound": r["bound"], "frac": r["frac"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"],
+                                       "valu_issue": {"frac": (r.get("valu_issue") or {}).get("frac")}, "lane_utilization": r.get("lane_utilization"),
+                                       "traffic": r.get("traffic"), "extrapolated": r.get("extrapolated"), "pmc_source": a_path}
+                    if r.get("stale_profile"):
+                        res["roofline"]["stale_profile"] = r["stale_profile"]
+                else:
+                    res["roofline"] = {"bound": "valu", "frac": None, "traffic": None, "pmc_source": None}
+            return res
+        also = {"book1_random_spheres_1200x800x500spp": dict(anchor("book1", 500, 5, "book1"), baseline_config="configs[2] on ONE GPU (north_star target frame)"),
+                "book2_final_scene_800x800x1000spp": dict(anchor("book2", 1000, 3, "book2"), baseline_config="configs[3]"),
+                # NOT the reference's tree: the surface-area-heuristic builder renders the identical image
+                # (tests/test_parity_gpu.py::test_sah_tree_renders_the_reference_tree_frame_at_c2) with fewer Aabb::hit calls
+                "book1_random_spheres_1200x800x50spp_sah_tree": dict(anchor("book1", 50, 5, None, bvh="sah"), baseline_config=None,
+                                                                     note="non-reference Bvh shape (SAH builder), identical image; not the headline")}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -339,6 +386,11 @@ def main():
             },
             "roofline": roof,
         }
+        if per_rank is not None:
+            line["per_rank"] = per_rank
+            # rank 0 receives the frame: its reduce time with the slowest rank's kernel taken out is the transfer itself
+            line["reduce_ms_avg"] = per_rank[0]["reduce_ms_avg"]
+            line["slowest_rank_kernel_ms"] = max(r["kernel_ms_avg"] for r in per_rank)
         if also is not None:
             line["also"] = also
         if verified is not None:

@@ -168,7 +168,7 @@ int rtg_par_cast_device(rtg_scene* s, const rtg_camera* camera, const rtg_params
 
 /* Single-process multi-GPU par_cast (SURVEY.md 8b `rtg_render_multi`; reference seam lib.rs:363-376): `scenes[i]` is
  * the SAME world flattened onto device i's HBM (rtg_scene_create with that device index; the scene is small and
- * read-only, so it is replicated).  Scene i renders the 16x16 pixel tiles with tile_index % n_scenes == i into a
+ * read-only, so it is replicated).  Scene i renders the pixel tiles (params->tile_w x tile_h; 0 = 16x16, 8x8 from 8 scenes on) with tile_index % n_scenes == i into a
  * zero-filled full frame on its device -- pixels, not samples, are sharded, so every pixel keeps the reference's
  * ordered sample fold -- then ONE collective, ncclReduce(sum) of the float3 framebuffer to the first device over
  * RCCL / xGMI (librccl is dlopen()ed on first use with > 1 distinct device), assembles the frame: x + 0 is exact, the

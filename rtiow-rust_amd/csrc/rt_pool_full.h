@@ -92,6 +92,14 @@ inline size_t full_pool_wg_words(uint32_t waves) { return (size_t)waves * FPOOL 
 #define RT_DRAIN_SHARE 1
 #endif
 constexpr uint32_t DQ_CAP = 256;                                   // records of a workgroup's hand-over stack
+// Control words in LDS.  INVARIANT the lock-free exit test relies on (it reads DC_HUNGRY and DC_COUNT without the lock):
+//  * a wave registers as hungry only under the lock, and only when it adopted nothing (k == 0, i.e. DC_COUNT was 0 then);
+//    a wave that adopts stores DC_COUNT before DC_HUNGRY, so a reader that sees the smaller DC_HUNGRY also sees the smaller count;
+//  * only a wave that still holds rays adds to DC_COUNT, and such a wave is not hungry: DC_HUNGRY == n_waves therefore means no
+//    wave can add records any more, and with DC_COUNT == 0 this is the terminal state -- it is reached exactly once, by the last
+//    non-hungry wave registering under the lock;
+//  * every wave of the workgroup takes part until then: a kernel variant in which a wave returns early, or skips the hand-over
+//    block, would leave the others polling for ever.  Debug builds (-DRT_DRAIN_WATCHDOG=<polls>) trap instead of hanging the GPU.
 enum DrainCtl : uint32_t { DC_LOCK = 0, DC_COUNT = 1, DC_HUNGRY = 2, DC_WORDS = 16 };
 // LDS = the first `window` program records (all of them when the program fits, 0 = none) + the hand-over control words
 inline size_t full_pool_lds_bytes(uint32_t window, uint32_t /*waves*/) { return (size_t)window * 32 + DC_WORDS * 4; }
@@ -216,6 +224,9 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   uint32_t* ctl = reinterpret_cast<uint32_t*>(s_mem + 2u * (USE_LDS ? window : 0u));  // hand-over control words behind the program
   if (threadIdx.x < DC_WORDS) ctl[threadIdx.x] = 0u;
   bool hungry = false;  // this wave has run dry and is counted in ctl[DC_HUNGRY] (wave-uniform)
+#ifdef RT_DRAIN_WATCHDOG
+  uint32_t drain_polls = 0;
+#endif
   const QueueRsrc qr = make_queue_rsrc(tq);                  // rows: T, then S (+X), then G (+R) -- see Q_ROW
   float* stack = uniform_ptr(g_stack + gwave * (STACK_LEVELS * 6 * 64));  // [level][component][lane]; level 0 rides in registers
   for (uint32_t j = lane; j < FPOOL; j += 64u) NQ_ST_U(NQ_SAMPLE, j, NQ_NEED_ITEM);  // FPOOL paths-to-be ask for a work item
@@ -691,6 +702,9 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           if (hungry && __builtin_amdgcn_readfirstlane(pool_lds_ld(ctl + DC_HUNGRY)) == n_waves &&
               __builtin_amdgcn_readfirstlane(pool_lds_ld(ctl + DC_COUNT)) == 0u) break;
           __builtin_amdgcn_s_sleep(127);  // (poll every ~3.5 us)
+#ifdef RT_DRAIN_WATCHDOG
+          if (++drain_polls > (uint32_t)(RT_DRAIN_WATCHDOG)) __builtin_trap();  // a regression of the invariant above shows as an error, not as a hung GPU
+#endif
           continue;
         }
 #endif

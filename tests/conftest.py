@@ -63,3 +63,16 @@ def free_port():
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         return sk.getsockname()[1]
+
+
+def retry_on_busy_port(run, attempts=3):
+    """free_port() closes its socket before the rendezvous binds the number: another process may take it in between.
+    `run(port)` starts the ranks and returns (returncode, stderr text); a failed start whose stderr names the address is
+    repeated on a fresh port (anything else is returned as it is)."""
+    last = None
+    for _ in range(attempts):
+        last = run(free_port())
+        rc, err = last
+        if rc == 0 or not any(k in (err or "") for k in ("Address already in use", "EADDRINUSE", "address already in use", "errno: 98")):
+            return last
+    return last

@@ -36,11 +36,16 @@ def test_two_rank_gloo_reduce_equals_single_frame(tmp_path, pkg, oracle):
     out = str(tmp_path / "frame.npy")
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
-    from conftest import free_port
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, str(script), out], env=dict(env, RANK=str(r))) for r in range(2)]
-    for p in procs:
-        assert p.wait(timeout=300) == 0
+    from conftest import retry_on_busy_port
+
+    def run(port):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+        procs = [subprocess.Popen([sys.executable, str(script), out], env=dict(env, RANK=str(r)), stderr=subprocess.PIPE, text=True)
+                 for r in range(2)]
+        errs = [p.communicate(timeout=300)[1] for p in procs]
+        return max(abs(p.returncode) for p in procs), "\n".join(errs)
+    rc, err = retry_on_busy_port(run)
+    assert rc == 0, err[-2000:]
     scene, cam, nx, ny, ns = build_case(pkg, oracle, "book1", 64, 48)
     assert_bit_equal(np.load(out), scene.par_cast(cam, nx, ny, ns), "2-rank sharded frame")
 
