@@ -59,12 +59,16 @@ def test_fuzz_graphs_bit_exact(pkg, gpu, oracle, seed):
     assert bytes(cam_g) == bytes(cam_o)
     sg, so = bg.scene(wg), bo.scene(wo)
     img_o, st_o = so.par_cast(cam_o, nx, ny, ns, stats=True)
-    img_g, st_g = sg.par_cast(cam_g, nx, ny, ns, stats=True)
-    assert_bit_equal(img_g, img_o, "fuzz scene %d" % seed)
-    for k in ("aabb_tests", "prim_tests", "shaded_hits", "rays", "draws"):
-        assert st_g[k] == st_o[k], (seed, k, st_g[k], st_o[k])
-    # ... and the timed instantiation of the same kernel (no counters: other register allocation, other spills)
-    assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns), img_o, "fuzz scene %d, production variant" % seed)
+    # a frame this small is routed to the lock-step kernel by default (rtg_launch.inc: tiny frames): both schedules, explicitly
+    # (programs the pool kernels do not take -- lean ones, FEAT_DEEP -- ignore the option)
+    for sync in (0, 1):
+        sg.set_option("sync", sync)
+        img_g, st_g = sg.par_cast(cam_g, nx, ny, ns, stats=True)
+        assert_bit_equal(img_g, img_o, "fuzz scene %d sync=%d" % (seed, sync))
+        for k in ("aabb_tests", "prim_tests", "shaded_hits", "rays", "draws"):
+            assert st_g[k] == st_o[k], (seed, sync, k, st_g[k], st_o[k])
+        # ... and the timed instantiation of the same kernel (no counters: other register allocation, other spills)
+        assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns), img_o, "fuzz scene %d sync=%d, production variant" % (seed, sync))
 
 
 @pytest.mark.gpu
@@ -76,11 +80,13 @@ def test_fuzz_graph_boundaries_bit_exact(pkg, gpu, oracle, seed):
     bo, wo, cam_o = _build(pkg, oracle, 5000 + seed, nx, ny, True)
     sg, so = bg.scene(wg), bo.scene(wo)
     img_o, st_o = so.par_cast(cam_o, nx, ny, ns, stats=True)
-    img_g, st_g = sg.par_cast(cam_g, nx, ny, ns, stats=True)
-    assert_bit_equal(img_g, img_o, "boundary fuzz scene %d" % seed)
-    for k in ("aabb_tests", "prim_tests", "shaded_hits", "rays", "draws"):
-        assert st_g[k] == st_o[k], (seed, k, st_g[k], st_o[k])
-    assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns), img_o, "boundary fuzz scene %d, production variant" % seed)
+    for sync in (0, 1):   # pool kernel and lock-step kernel (see test_fuzz_graphs_bit_exact)
+        sg.set_option("sync", sync)
+        img_g, st_g = sg.par_cast(cam_g, nx, ny, ns, stats=True)
+        assert_bit_equal(img_g, img_o, "boundary fuzz scene %d sync=%d" % (seed, sync))
+        for k in ("aabb_tests", "prim_tests", "shaded_hits", "rays", "draws"):
+            assert st_g[k] == st_o[k], (seed, sync, k, st_g[k], st_o[k])
+        assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns), img_o, "boundary fuzz scene %d sync=%d, production variant" % (seed, sync))
 
 
 N_DEEP_SCENES = 24
