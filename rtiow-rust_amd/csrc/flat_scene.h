@@ -105,6 +105,12 @@ constexpr uint32_t FEAT_TEXTURE = 8u;  // a non-constant texture is referenced
 constexpr uint32_t FEAT_BOUNDARY = 16u; // a ConstantMedium whose boundary is an object graph (nested boundary walk)
 constexpr uint32_t FEAT_DEEP = 128u;   // a graph shape only the general walk handles (rt_trace.h walk_deep, baseline kernel): more than MAX_XFORM_DEPTH
                                        // nested wrappers, a medium inside a medium's boundary, a medium below an And below a Bvh
+// Only together with FEAT_DEEP, chosen per scene from the depths the flattener measured (FlatScene::deep_wrappers / deep_media):
+// which instantiation of the general walk renders it.  The walk's private stacks are sized by its template parameters --
+// 32 wrapper levels x 4 nesting levels of media is 4.2 KB of scratch per lane and 178 VGPRs whatever the graph needs.
+constexpr uint32_t FEAT_DEEP_FEW_WRAPPERS = 256u;  // no more than DEEP_FEW_WRAPPERS wrappers are ever open at once: ray stacks of 8 instead of 32
+constexpr uint32_t FEAT_DEEP_ONE_LEVEL = 512u;     // no medium inside a medium's boundary: the walk recurses one level (its boundary queries), not three
+constexpr int DEEP_FEW_WRAPPERS = 8;
 constexpr uint32_t FEAT_BRIGHT_ALBEDO = 64u; // an albedo component may exceed 1 (a constant in (1, 4], or Perlin turbulence, <= 3.47): the pool
                                             // kernels then need max_bounces <= 63 for the strength to stay finite
 constexpr uint32_t FEAT_WIDE_ALBEDO = 32u;  // an albedo component outside [0, 4]: path strength may overflow or change sign, so the pool

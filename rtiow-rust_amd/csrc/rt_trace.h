@@ -281,7 +281,9 @@ __device__ __attribute__((noinline)) BoundaryHit boundary_hit_t(const uint4* __r
 // the closest t matters) -- a medium met at LEVEL n runs its two queries at LEVEL n + 1 over its boundary's record stream, with
 // the event's RNG stream handed down so that the draws happen in the reference's order (object.rs:562).  Same predicates,
 // same visiting order, same counters as hit_top / boundary_hit_t; one lane per ray, private stacks: the slow, general path.
-template <int LEVEL, bool COUNT>
+// XD = wrapper levels the ray stacks hold, ML = levels of boundary queries below the main walk: chosen per scene by what its graph
+// needs (FEAT_DEEP_FEW_WRAPPERS / FEAT_DEEP_ONE_LEVEL) -- the stacks are private memory and registers of every lane.
+template <int LEVEL, bool COUNT, int XD = MAX_DEEP_XFORM_DEPTH, int ML = MAX_MEDIUM_NESTING>
 __device__ __attribute__((noinline)) bool walk_deep(const DevScene& sc, uint32_t first, uint32_t end_pc, V3 o, V3 d, const float time,
                                                     const float t_lo, const float t_hi, SampleRng& rng, HitRec* rec, float& t_out,
                                                     Counts& cnt) {
@@ -290,7 +292,7 @@ __device__ __attribute__((noinline)) bool walk_deep(const DevScene& sc, uint32_t
   bool any = false;
   int depth = 0, tag = 0, sp = 0;
   uint32_t nhits = 0, root_hits = 0;
-  V3 so[MAX_DEEP_XFORM_DEPTH], sd[MAX_DEEP_XFORM_DEPTH];
+  V3 so[XD], sd[XD];
   // OP_SAVE .. OP_MERGE: the hit in front of an And-with-medium leaf of a Bvh
   float sv_best[MAX_SAVE_NESTING];
   HitRec sv_rec[MAX_SAVE_NESTING];
@@ -403,14 +405,14 @@ __device__ __attribute__((noinline)) bool walk_deep(const DevScene& sc, uint32_t
       float t1 = 0.f, t2 = 0.f;
       bool h1 = false, h2 = false;
       if (general) {
-        if constexpr (LEVEL < MAX_MEDIUM_NESTING) h1 = walk_deep<LEVEL + 1, COUNT>(sc, pc + 1, hi.x, o, d, time, -F32_MAX, F32_MAX, rng, nullptr, t1, cnt);
+        if constexpr (LEVEL < ML) h1 = walk_deep<LEVEL + 1, COUNT, XD, ML>(sc, pc + 1, hi.x, o, d, time, -F32_MAX, F32_MAX, rng, nullptr, t1, cnt);
       } else {
         if (COUNT) cnt.prim++;
         h1 = prim_hit_t(blo, bhi, o, d, -F32_MAX, F32_MAX, t1);
       }
       if (h1) {
         if (general) {
-          if constexpr (LEVEL < MAX_MEDIUM_NESTING) h2 = walk_deep<LEVEL + 1, COUNT>(sc, pc + 1, hi.x, o, d, time, t1 + 0.0001f, F32_MAX, rng, nullptr, t2, cnt);
+          if constexpr (LEVEL < ML) h2 = walk_deep<LEVEL + 1, COUNT, XD, ML>(sc, pc + 1, hi.x, o, d, time, t1 + 0.0001f, F32_MAX, rng, nullptr, t2, cnt);
         } else {
           if (COUNT) cnt.prim++;
           h2 = prim_hit_t(blo, bhi, o, d, t1 + 0.0001f, F32_MAX, t2);
@@ -464,7 +466,9 @@ RT_DEV bool hit_top(const DevScene& sc, V3 o, V3 d, float time, float t_near, Sa
   if (COUNT) cnt.rays++;
   if (FEAT & FEAT_DEEP) {  // graph shapes only the general walk handles
     float t;
-    return walk_deep<0, COUNT>(sc, 0u, sc.n_prog, o, d, time, t_near, F32_MAX, rng, &rec, t, cnt);
+    constexpr int XD = (FEAT & FEAT_DEEP_FEW_WRAPPERS) ? DEEP_FEW_WRAPPERS : MAX_DEEP_XFORM_DEPTH;
+    constexpr int ML = (FEAT & FEAT_DEEP_ONE_LEVEL) ? 1 : MAX_MEDIUM_NESTING;
+    return walk_deep<0, COUNT, XD, ML>(sc, 0u, sc.n_prog, o, d, time, t_near, F32_MAX, rng, &rec, t, cnt);
   }
   V3 inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);  // aabb.rs:17, hoisted: depends on the ray only
   float best = F32_MAX;

@@ -413,6 +413,7 @@ void SceneBuilder::emit(uint32_t id, bool under_bvh, int depth, FlatScene* out, 
         if (single) {
           fuse_primitive(*this, o.a, out, true, false);
         } else {
+          out->deep_media = std::max(out->deep_media, boundary + 1);
           emit(o.a, false, 0, out, boundary + 1, holds_medium(o.a), 0), out->features |= FEAT_BOUNDARY;
           push(out, 0, 0, 0, 0, 0, 0, (uint32_t)at, OP_BEND);  // where a range-query walk of the stream finishes
         }
@@ -435,6 +436,7 @@ void SceneBuilder::emit(uint32_t id, bool under_bvh, int depth, FlatScene* out, 
   }
   if (depth >= MAX_DEEP_XFORM_DEPTH)
     throw BuildError{-5, "transform wrappers nested deeper than the general walk's ray stack (32)"};
+  out->deep_wrappers = std::max(out->deep_wrappers, depth + 1);
   if (depth >= MAX_XFORM_DEPTH) out->features |= FEAT_DEEP;  // deeper than the scheduled kernels' ray stack: the general walk
   out->features |= FEAT_XFORM;
   // Translate{RotateY{x}} / Translate{LinearMove{x}} (every transformed object of main.rs): one wrapper level
@@ -481,6 +483,10 @@ void SceneBuilder::flatten(const uint32_t* world, size_t n, FlatScene* out) cons
   const bool full_pool = has_box && (out->features & (FEAT_XFORM | FEAT_MEDIUM | FEAT_RECT | FEAT_TEXTURE | FEAT_BOUNDARY)) != 0u &&
                          !(out->features & FEAT_DEEP);
   if (hoist_segments && full_pool && seg1 > seg0) flatten_program(world, n, out, seg0, seg1);
+  if (out->features & FEAT_DEEP) {  // which instantiation of the general walk this graph needs (flat_scene.h)
+    if (out->deep_wrappers <= DEEP_FEW_WRAPPERS) out->features |= FEAT_DEEP_FEW_WRAPPERS;
+    if (out->deep_media <= 1) out->features |= FEAT_DEEP_ONE_LEVEL;
+  }
   finish_materials(out);
 }
 
@@ -488,6 +494,7 @@ void SceneBuilder::flatten(const uint32_t* world, size_t n, FlatScene* out) cons
 void SceneBuilder::flatten_program(const uint32_t* world, size_t n, FlatScene* out, size_t seg0, size_t seg1) const {
   out->lo.clear(), out->hi.clear(), out->mat.clear(), out->tex.clear();
   out->features = 0;
+  out->deep_wrappers = 0, out->deep_media = 0;
   // Runs of consecutive list-level objects that hold no Bvh are straight-line code every ray executes in
   // the same order: their first record is marked F_GATHER so a scheduler can batch the rays there.  (The records of a hoisted
   // segment do not count: a kernel that commits the segment at its OP_SEG record never executes them.)

@@ -54,6 +54,8 @@ struct FlatScene {
   std::array<uint8_t, 768> perlin_perm{};
   uint32_t features = 0;
   bool has_perlin = false;
+  int deep_wrappers = 0;  // most wrappers (PUSH) open at once in any one stream of the program
+  int deep_media = 0;     // deepest level of boundary queries a walk of the program recurses into (0 = no object-graph boundary)
 };
 
 class SceneBuilder {

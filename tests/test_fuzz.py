@@ -171,3 +171,43 @@ def test_fuzz_deep_shapes_bit_exact(pkg, gpu, oracle, seed):
     for k in ("aabb_tests", "prim_tests", "shaded_hits", "rays", "draws"):
         assert st_g[k] == st_o[k], (seed, k, st_g[k], st_o[k])
     assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns), img_o, "deep fuzz scene %d, production variant" % seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wrappers,media_levels", [(6, 1), (12, 1), (30, 1), (6, 3), (12, 3)])
+def test_general_walk_sized_by_the_graph(pkg, gpu, oracle, wrappers, media_levels):
+    """FEAT_DEEP graphs run an instantiation of the general walk sized for what they need (flat_scene.h FEAT_DEEP_FEW_WRAPPERS =
+    256: <= 8 wrappers open at once, FEAT_DEEP_ONE_LEVEL = 512: no medium inside a medium's boundary).  Every combination --
+    few / many wrappers x one / three levels -- against the oracle, and against the largest instantiation (option deep_sized = 0)."""
+    S = pkg.scenes
+    nx, ny, ns = 48, 32, 6
+
+    def build(be):
+        b = be.builder()
+        m = b.lambertian(b.constant(S.v(0.6, 0.5, 0.4)))
+        iso = b.isotropic(b.constant(S.vfrom(0.9)))
+        inner = b.sphere(1.0, m)
+        for i in range(wrappers):   # alternating wrapper kinds, `wrappers` levels deep
+            inner = (b.translate(S.v(0.01 * i, 0.0, 0.0), inner) if i % 3 == 0 else
+                     b.rotate_y(3.0, inner) if i % 3 == 1 else b.scale(S.v(1.0, 1.02, 1.0), inner))
+        level = b.sphere(0.8, m)
+        for _ in range(media_levels):   # a medium whose boundary holds a medium whose boundary ...
+            level = b.constant_medium(b.and_(b.rect_prism(S.v(-1.5, -1.5, -1.5), S.v(1.5, 1.5, 1.5), m), level), 0.4, iso)
+        world = [inner, b.translate(S.v(3.0, 0.0, 0.0), level),
+                 b.flip_normals(b.sphere(50.0, b.diffuse_light(b.constant(S.v(0.7, 0.8, 1.0)), 1.0)))]
+        cam = be.camera_look(S.v(1.5, 1.0, 9.0), S.v(1.5, 0.0, 0.0), S.v(0.0, 1.0, 0.0), 35.0, nx / ny, 0.0, 10.0)
+        return b, world, cam
+    bg, wg, cam_g = build(gpu)
+    bo, wo, cam_o = build(oracle)
+    _, feat = bg.flatten(wg)
+    assert feat & 128
+    assert bool(feat & 256) == (wrappers <= 8) and bool(feat & 512) == (media_levels <= 1), hex(feat)
+    sg, so = bg.scene(wg), bo.scene(wo)
+    img_o, st_o = so.par_cast(cam_o, nx, ny, ns, stats=True)
+    for sized in (1, 0):
+        sg.set_option("deep_sized", sized)
+        img_g, st_g = sg.par_cast(cam_g, nx, ny, ns, stats=True)
+        assert_bit_equal(img_g, img_o, "wrappers %d, media levels %d, deep_sized %d" % (wrappers, media_levels, sized))
+        for k in ("aabb_tests", "prim_tests", "shaded_hits", "rays", "draws"):
+            assert st_g[k] == st_o[k], (wrappers, media_levels, sized, k)
+        assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns), img_o, "production variant")
