@@ -40,6 +40,8 @@ python tools/tail_probe.py book2 800 800 > $O/tail_probe_book2.txt 2>&1
 python tools/criterion_scene.py > $O/criterion_scene.txt 2>&1
 python tools/latency_probe.py > $O/latency_probe.txt 2>&1
 python tools/shard_time.py > $O/shard_time.txt 2>&1
+python tools/probe_book2_levers.py > $O/book2_levers.txt 2>&1
+python tools/time_deep_fuzz.py > $O/deep_fuzz.txt 2>&1
 python -m pytest tests -m gpu -q --timeout=300 > $O/pytest_gpu.log 2>&1
 ls -la $O
 # where the waves wait (tools/pmc_wait.sh): issue / wait-to-issue / s_waitcnt shares of the wave-cycles, per instruction class
