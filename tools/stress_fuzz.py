@@ -3,7 +3,8 @@
 counters.  usage: stress_fuzz.py <first seed> <last seed>   [FZ_NX / FZ_NY / FZ_NS = frame size and samples; FZ_DEEP=1: every
 third graph is drawn with the shapes only the general walk handles (FEAT_DEEP)]"""
 import sys, os
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import __graft_entry__ as g
 from fuzz_scenes import random_camera, random_world
@@ -22,9 +23,18 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         cam = random_camera(pkg, be, rs, int(os.environ.get("FZ_NX", "64")), int(os.environ.get("FZ_NY", "40")))
         sc = b.scene(w)
         if be is gpu:
-            img, st = sc.par_cast(cam, int(os.environ.get("FZ_NX", "64")), int(os.environ.get("FZ_NY", "40")), int(os.environ.get("FZ_NS", "12")), stats=True)
-            img2 = sc.par_cast(cam, int(os.environ.get("FZ_NX", "64")), int(os.environ.get("FZ_NY", "40")), int(os.environ.get("FZ_NS", "12")))
-            imgs.append((img, st, img2))
+            # both schedules of the full-feature path: pool kernel (sync 0) and lock-step kernel (sync 1); lean / FEAT_DEEP programs ignore the option
+            runs = []
+            for sync in (0, 1):
+                sc.set_option("sync", sync)
+                img, st = sc.par_cast(cam, int(os.environ.get("FZ_NX", "64")), int(os.environ.get("FZ_NY", "40")), int(os.environ.get("FZ_NS", "12")), stats=True)
+                img2 = sc.par_cast(cam, int(os.environ.get("FZ_NX", "64")), int(os.environ.get("FZ_NY", "40")), int(os.environ.get("FZ_NS", "12")))
+                runs.append((img, st, img2))
+            if not (np.array_equal(runs[0][0].view(np.uint32), runs[1][0].view(np.uint32)) and np.array_equal(runs[0][2].view(np.uint32), runs[1][2].view(np.uint32))
+                    and all(runs[0][1][k] == runs[1][1][k] for k in ("aabb_tests", "prim_tests", "shaded_hits", "rays", "draws"))):
+                bad += 1
+                print("MISMATCH between the two schedules, seed", seed)
+            imgs.append(runs[0])
         else:
             img, st = sc.par_cast(cam, int(os.environ.get("FZ_NX", "64")), int(os.environ.get("FZ_NY", "40")), int(os.environ.get("FZ_NS", "12")), stats=True)
             imgs.append((img, st))
