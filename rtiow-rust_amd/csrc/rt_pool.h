@@ -291,6 +291,9 @@ struct LaunchConsts {
   DevParams P;
   ChunkMode cm;
   PixMap pm;
+  uint32_t mat_lds;             // full-feature kernels: byte offset of the material records' copy in LDS (behind the program and, in the pool kernel, its
+                                // control words), 0 = they do not fit: fetched from global memory.  A shade pass's material fetch is a dependent load
+                                // behind the hit's material index: from LDS it costs ~130 cycles instead of a trip to L2 (~1 500)
   uint32_t seg_first, seg_end;  // full-feature pool kernel: the records of the hoisted segment as program counters (flat_scene.h OP_SEG);
                                 // seg_end = 0: no segment, or hoisting switched off -- OP_SEG is then stepped over
 };

@@ -102,7 +102,7 @@ constexpr uint32_t DQ_CAP = 256;                                   // records of
 //    block, would leave the others polling for ever.  Debug builds (-DRT_DRAIN_WATCHDOG=<polls>) trap instead of hanging the GPU.
 enum DrainCtl : uint32_t { DC_LOCK = 0, DC_COUNT = 1, DC_HUNGRY = 2, DC_WORDS = 16 };
 // LDS = the first `window` program records (all of them when the program fits, 0 = none) + the hand-over control words
-inline size_t full_pool_lds_bytes(uint32_t window, uint32_t /*waves*/) { return (size_t)window * 32 + DC_WORDS * 4; }
+inline size_t full_pool_lds_bytes(uint32_t window, uint32_t /*waves*/) { return (size_t)window * 32 + DC_WORDS * 4; }  // (+ the materials when they fit: rtg_launch.inc)
 
 // draw `idx` (0-based) of the stream (seed, pixel, sample, event): word idx%4 of Philox block idx/4
 __device__ __attribute__((always_inline)) float event_draw_f32_inline(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t event, uint32_t idx) {
@@ -214,6 +214,9 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
     }
   }
   const char* s_bytes = reinterpret_cast<const char*>(s_mem);
+  const uint32_t mat_lds = load_const(&lc->mat_lds);
+  if (mat_lds)
+    for (uint32_t i = threadIdx.x; i < 2u * sc.n_mat; i += blockDim.x) s_mem[(mat_lds >> 4) + i] = sc.mat[i];
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, n_waves = blockDim.x >> 6;
   const size_t gwave = (size_t)blockIdx.x * n_waves + wave;
   static_assert(DQ_CAP == 256u, "full_pool_wg_words");
@@ -367,7 +370,9 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           uint4 mlo = make_uint4(0, 0, 0, 0), mhi = make_uint4(0, 0, 0, 0);
           V3 texval = mk(0.f, 0.f, 0.f);
           if (hm != NO_HIT) {
-            mlo = sc.mat[2 * hm], mhi = sc.mat[2 * hm + 1];
+            const uint32_t m_off = load_const(&lc->mat_lds);
+            if (m_off) mlo = s_mem[(m_off >> 4) + 2u * hm], mhi = s_mem[(m_off >> 4) + 2u * hm + 1u];
+            else mlo = sc.mat[2 * hm], mhi = sc.mat[2 * hm + 1];
             texval = material_texture<PASS_FEAT>(sc, mlo, mhi, p);  // = albedo / emission colour for constant textures
           }
           sd = mk(SQ_LD_F(SQ_D, j), SQ_LD_F(SQ_D + 1, j), SQ_LD_F(SQ_D + 2, j));

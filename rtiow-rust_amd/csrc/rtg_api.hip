@@ -110,6 +110,7 @@ struct rtg_scene {
   int wg_per_cu = 0;                       // 0 = ask the occupancy API
   int full_threads = 0;                    // full-feature pool kernel: 0 = the variant's maximum (RTG_BLOCK overrides)
   int pool_threads = 0;                    // lean ray-pool kernel: 0 = ONE 16-wave workgroup per CU shares one LDS copy of the program (RTG_BLOCK overrides)
+  int mat_lds = 1;                          // full-feature kernels: material records staged in LDS when they fit (0 = always from global memory)
   int deep_sized = 1;                       // FEAT_DEEP graphs: the general walk instantiated for the graph's real depths (0 = always 32 wrappers x 3 media levels)
   int hoist = 1;                            // full-feature pool kernel: evaluate the hoisted segment when a ray is created (flat_scene.h OP_SEG); 0 = the walk executes its records
   uint32_t seg_first = 0, seg_end = 0;      // ... its records, as record indices (0, 0: the program has none)
@@ -545,6 +546,7 @@ int rtg_scene_set_option(rtg_scene* s, const char* name, int value) {
   else if (k == "drain_share") s->drain_share = value;
   else if (k == "hoist") s->hoist = value;
   else if (k == "deep_sized") s->deep_sized = value;
+  else if (k == "mat_lds") s->mat_lds = value;
   else if (k == "small_frames") s->small_frames = value;        // 0: one geometry for every frame size (measurement switch)
   else if (k == "verbose") s->verbose = value;                  // print launch geometry / schedule statistics to stderr
   else if (k == "window") s->window = value;                    // full-feature kernel: records staged in LDS, -1 = automatic
