@@ -291,6 +291,8 @@ struct LaunchConsts {
   DevParams P;
   ChunkMode cm;
   PixMap pm;
+  const uint32_t* parent;       // full-feature pool kernel: per program record, the index of the PUSH record of the innermost wrapper around it
+                                // (0xffffffff: none) -- what rebuild_hit replays (rt_pool_full.h)
   uint32_t mat_lds;             // full-feature kernels: byte offset of the material records' copy in LDS (behind the program and, in the pool kernel, its
                                 // control words), 0 = they do not fit: fetched from global memory.  A shade pass's material fetch is a dependent load
                                 // behind the hit's material index: from LDS it costs ~130 cycles instead of a trip to L2 (~1 500)

@@ -60,9 +60,10 @@ enum FullTField : uint32_t {  // T stack: a ray ready to traverse (the *_TRACE r
   TQ_SEG_T = 13, TQ_SEG_PC = 14,  // the hoisted segment's closest candidate for this ray (hoist_eval; flat_scene.h OP_SEG)
   TQ_TRACE = 15, TQ_FIELDS = 18,
 };
-enum FullSField : uint32_t {  // S / X stacks: a finished ray with its hit record
-  SQ_P = 0, SQ_N = 3, SQ_D = 6, SQ_TIME = 9, SQ_HITMAT = 10, SQ_EVDRAWS = 11, SQ_STRENGTH = 12, SQ_BOUNCES = 15, SQ_SAMPLE = 16,
-  SQ_XY = 17, SQ_TRACE = 18, SQ_FIELDS = 21,
+enum FullSField : uint32_t {  // S / X stacks: a finished ray with what the walk found -- t and the winning record (RT_DEFER_HIT: the hit
+                               // record itself is rebuilt by the shade pass, rebuild_hit)
+  SQ_O = 0, SQ_D = 3, SQ_TIME = 6, SQ_T = 7, SQ_HITPC = 8, SQ_EVDRAWS = 9, SQ_STRENGTH = 10, SQ_BOUNCES = 13, SQ_SAMPLE = 14,
+  SQ_XY = 15, SQ_TRACE = 16, SQ_FIELDS = 19,
 };
 enum FullNField : uint32_t { NQ_SAMPLE = 0, NQ_XY = 1, NQ_FIELDS = 2 };  // N stack: a path that ended asks for its successor
 constexpr uint32_t NQ_NEED_ITEM = 0xffffffffu;  // NQ_SAMPLE: "the next work item" instead of "sample s of the same pixel"
@@ -159,17 +160,19 @@ constexpr uint32_t XQ = SQ_FIELDS * FPOOL;  // X stack = positions XQ.. of the S
 // their own passes, so the Perlin / checker code is issued for 64 textured hits at a time instead of in every pass that
 // happens to hold one.
 template <bool TEX, bool TRACE>
-RT_DEV void full_push_finished(const QueueRsrc qr, uint32_t& s_count, uint32_t& x_count, const bool fin, const V3 fhp, const V3 fhn,
-                               const uint32_t fhmat, const V3 fd, const float ftime, const uint32_t fev, const V3 fstrength,
+RT_DEV void full_push_finished(const QueueRsrc qr, uint32_t& s_count, uint32_t& x_count, const bool fin, const V3 fo, const V3 fd,
+                               const float ftime, const float ft, const uint32_t fpc, const uint32_t fev, const V3 fstrength,
                                const uint32_t fbounces, const uint32_t fsample, const uint32_t fxy, const bool trace,
                                const uint32_t ft0, const uint32_t ft1, const uint32_t ft2) {
-  const bool to_x = TEX && fin && fhmat != NO_HIT && (fhmat >> 31) != 0u;
+  // bit 3 of the winning record's pc = its material reads a non-constant texture (F_TEXTURED): such hits are shaded in passes of
+  // their own, so the Perlin / checker code is issued for 64 textured hits at a time instead of in every pass that holds one
+  const bool to_x = TEX && fin && fpc != NO_HIT && (fpc & 8u) != 0u;
   const uint64_t m_fin = __builtin_amdgcn_ballot_w64(fin && !to_x), m_x = __builtin_amdgcn_ballot_w64(to_x);
   if (fin) {
     const uint32_t i = to_x ? XQ + x_count + lane_rank(m_x) : s_count + lane_rank(m_fin);
-    SQ_ST_U(SQ_HITMAT, i, fhmat == NO_HIT ? NO_HIT : (fhmat & 0x7fffffffu));
-    SQ_ST_F(SQ_P, i, fhp.x), SQ_ST_F(SQ_P + 1, i, fhp.y), SQ_ST_F(SQ_P + 2, i, fhp.z);
-    SQ_ST_F(SQ_N, i, fhn.x), SQ_ST_F(SQ_N + 1, i, fhn.y), SQ_ST_F(SQ_N + 2, i, fhn.z);
+    SQ_ST_U(SQ_HITPC, i, fpc);
+    SQ_ST_F(SQ_T, i, ft);
+    SQ_ST_F(SQ_O, i, fo.x), SQ_ST_F(SQ_O + 1, i, fo.y), SQ_ST_F(SQ_O + 2, i, fo.z);
     SQ_ST_F(SQ_D, i, fd.x), SQ_ST_F(SQ_D + 1, i, fd.y), SQ_ST_F(SQ_D + 2, i, fd.z);
     SQ_ST_F(SQ_TIME, i, ftime);
     SQ_ST_U(SQ_EVDRAWS, i, fev);
@@ -251,8 +254,8 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   float time = 0.f, best = F32_MAX;
   uint32_t pc = 0;
   uint4 cur_lo = make_uint4(0, 0, 0, 0), cur_hi = make_uint4(0, 0, 0, OP_END);
-  V3 hp = o, hn = o;                 // hit record (object.rs:61-71), in the space of wrapper depth `tag`
-  uint32_t hmat = NO_HIT;            // NO_HIT = None
+  V3 hp = o, hn = o;                 // (RT_DEFER_HIT: unused -- the hit record is rebuilt by the shade pass)
+  uint32_t hmat = NO_HIT;            // the winning record so far: pc | prism face | bit 3 "textured"; NO_HIT = None
   uint32_t depth = 0, tag = 0, nhits = 0, root_hits = 0, ev_draws = 0;
   uint32_t r_xy = 0, r_sample = 0, r_bounces = 0;  // the path's pixel (x | row << 16), sample and bounce count: its RNG stream for media
   V3 r_strength = o;                                // the path's strength rides along (lib.rs:77)
@@ -274,6 +277,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
 #endif
   unsigned long long t_shade = 0, t_serv = 0, t_box = 0, t_slow = 0, t_refill = 0, t_fin = 0, n_serv = 0, t_mark = 0, t_mark2 = 0;  // COUNT: s_memtime shares
 
+#define RT_DEFER_HIT 1   // hits are (t, record pc): rt_full_ops.inc
 #define RT_HOIST 1       // OP_SEG commits the candidate hoist_eval found when the ray was created
 #define RT_REG_STACK0 1  // PUSH / POP of an outermost wrapper touch no memory (book-2: the moving sphere, the sphere cloud)
 #ifndef RT_POOL_SAME_KIND_RUN
@@ -284,6 +288,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
 #undef RT_SAME_KIND_RUN
 #undef RT_REG_STACK0
 #undef RT_HOIST
+#undef RT_DEFER_HIT
   // The hoisted segment (flat_scene.h OP_SEG) for a ray that is being created: Sphere::hit / Rect::hit / rect_prism's six
   // Rect::hit for every record of the segment in order against a shrinking t -- exactly what the walk would do with
   // t_range.end = f32::MAX -- keeping the closest candidate.  Called by the shade and camera passes with every lane on the
@@ -302,17 +307,85 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           const uint4 mv = RT_FETCH_LO(q + RSZ);
           lo_o = vsub(lo_o, smul(rtime, mk(u2f(mv.x), u2f(mv.y), u2f(mv.z))));
         }
-        if (sphere_hit_t(lo_o, rd, u2f(q_lo.w), t_near, c_t, t)) c_t = t, c_pc = q;
+        if (sphere_hit_t(lo_o, rd, u2f(q_lo.w), t_near, c_t, t)) c_t = t, c_pc = q | ((w >> 16) & 8u);
         n_tests += 1u;
         if (w & F_MOVE) q += RSZ;
       } else if (q_op == OP_RECT) {
         if (rect_hit_t(ro, rd, (w >> F_AXIS_SHIFT) & 3u, u2f(q_lo.x), u2f(q_lo.y), u2f(q_lo.z), u2f(q_lo.w), u2f(q_hi.x), t_near, c_t, t))
-          c_t = t, c_pc = q;
+          c_t = t, c_pc = q | ((w >> 16) & 8u);
         n_tests += 1u;
       } else if (q_op == OP_PRISM) {
         uint32_t face = 0;
-        if (prism_hit_t(q_lo, q_hi, ro, rd, t_near, c_t, t, face)) c_t = t, c_pc = q | face;
+        if (prism_hit_t(q_lo, q_hi, ro, rd, t_near, c_t, t, face)) c_t = t, c_pc = q | face | ((w >> 16) & 8u);
         n_tests += 6u;
+      }
+    }
+  };
+
+  // The hit record (object.rs:61-71) of a finished ray, from the ray, t and the winning record -- what the walk would have built
+  // at the hit and carried through the POPs, operation for operation: the wrappers around the record (flattened parent table,
+  // outermost first) turn the ray into the one the primitive was tested with (object.rs:275-278, 357-361, 309-313, 505-508), the
+  // primitive builds (p, normal) as its `hit` does, the wrappers take the record back out, innermost first (object.rs:279-282,
+  // 365-369, 314-318, 249-252).  Same operands, same order: the same bits.
+  auto rebuild_hit = [&](const uint32_t bpc, V3 ro, V3 rd, const float rtime, const float t, V3& p, V3& n, uint32_t& mat) {
+    constexpr uint32_t NONE = 0xffffffffu;
+    const uint32_t rpc = bpc & ~(RSZ - 1u);
+    const uint32_t* par = load_const(&lc->parent);
+    uint32_t w0 = par[rpc >> 5], w1 = NONE, w2 = NONE, w3 = NONE;  // enclosing PUSH records, innermost first (<= MAX_XFORM_DEPTH)
+    if (w0 != NONE) w1 = par[w0];
+    if (w1 != NONE) w2 = par[w1];
+    if (w2 != NONE) w3 = par[w2];
+#pragma unroll 1
+    for (int k = 3; k >= 0; k--) {  // in
+      const uint32_t w = k == 3 ? w3 : k == 2 ? w2 : k == 1 ? w1 : w0;
+      if (w != NONE) {
+        const uint4 x_lo = RT_FETCH_LO(w * RSZ), x_hi = RT_FETCH_HI(w * RSZ);
+        const uint32_t kind = (x_hi.w >> F_KIND_SHIFT) & 7u;
+        const V3 a = mk(u2f(x_lo.x), u2f(x_lo.y), u2f(x_lo.z));
+        if (x_hi.w & F_PRE_TRANSLATE) ro = vsub(ro, mk(u2f(x_lo.w), u2f(x_hi.x), u2f(x_hi.y)));
+        if (kind == XF_TRANSLATE) ro = vsub(ro, a);
+        else if (kind == XF_ROTATE_Y) ro = rot_y(ro, -a.x, a.y), rd = rot_y(rd, -a.x, a.y);
+        else if (kind == XF_SCALE) ro = vdiv(ro, a), rd = vdiv(rd, a);
+        else if (kind == XF_MOVE) ro = vsub(ro, smul(rtime, a));
+      }
+    }
+    const uint4 r_lo = RT_FETCH_LO(rpc), r_hi = RT_FETCH_HI(rpc);
+    const uint32_t r_op = r_hi.w & 0xffu;
+    mat = r_hi.z;
+    if (r_op == OP_SPHERE) {
+      const V3 off = mk(u2f(r_lo.x), u2f(r_lo.y), u2f(r_lo.z));
+      V3 lo_o = ro;
+      if (r_hi.w & F_TRANSLATE) lo_o = vsub(ro, off);
+      if (r_hi.w & F_MOVE) {
+        const uint4 mv = RT_FETCH_LO(rpc + RSZ);
+        lo_o = vsub(lo_o, smul(rtime, mk(u2f(mv.x), u2f(mv.y), u2f(mv.z))));
+      }
+      p = vadd(lo_o, smul(t, rd));
+      n = sdiv(p, u2f(r_lo.w));
+      if (r_hi.w & F_TRANSLATE) p = vadd(p, off);
+      if (r_hi.w & F_FLIP) n = vneg(n);
+    } else if (r_op == OP_RECT) {
+      const uint32_t axis = (r_hi.w >> F_AXIS_SHIFT) & 3u;
+      n = mk(axis == 0 ? 1.f : 0.f, axis == 1 ? 1.f : 0.f, axis == 2 ? 1.f : 0.f);
+      if (r_hi.w & F_FLIP) n = vneg(n);
+      p = vadd(ro, smul(t, rd));
+    } else if (r_op == OP_PRISM) {
+      p = vadd(ro, smul(t, rd)), n = prism_normal(bpc & 7u);
+    } else {  // MEDIUM: object.rs:567-571
+      p = vadd(ro, smul(t, rd)), n = mk(1.f, 0.f, 0.f);
+    }
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) {  // out
+      const uint32_t w = k == 3 ? w3 : k == 2 ? w2 : k == 1 ? w1 : w0;
+      if (w != NONE) {
+        const uint4 x_lo = RT_FETCH_LO(w * RSZ), x_hi = RT_FETCH_HI(w * RSZ);
+        const uint32_t kind = (x_hi.w >> F_KIND_SHIFT) & 7u;
+        const V3 a = mk(u2f(x_lo.x), u2f(x_lo.y), u2f(x_lo.z));
+        if (kind == XF_TRANSLATE) p = vadd(p, a);
+        else if (kind == XF_ROTATE_Y) p = rot_y(p, a.x, a.y), n = rot_y(n, a.x, a.y);
+        else if (kind == XF_SCALE) p = vmul(p, a), n = vdiv(n, a);
+        else if (kind == XF_FLIP) n = vneg(n);
+        if (x_hi.w & F_PRE_TRANSLATE) p = vadd(p, mk(u2f(x_lo.w), u2f(x_hi.x), u2f(x_hi.y)));
       }
     }
   };
@@ -333,7 +406,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
       if (COUNT) t_mark = RT_TICK();
       {  // (1) finish (depth is 0 again, so o / d are the ray's own)
         const bool fin = have_ray && op == OP_END;
-        full_push_finished<TEX, COUNT>(qr, s_count, x_count, fin, hp, hn, hmat, d, time, ev_draws, r_strength, r_bounces, r_sample, r_xy,
+        full_push_finished<TEX, COUNT>(qr, s_count, x_count, fin, o, d, time, best, hmat, ev_draws, r_strength, r_bounces, r_sample, r_xy,
                                        tr_out != nullptr, tr_d + ev_draws, tr_a + (cnt.aabb - tr_a0), tr_p + (cnt.prim - tr_p0));
         if (fin) have_ray = false;
       }
@@ -358,25 +431,28 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         float stime = 0.f;
         uint32_t bounces = 0, s = 0, x = 0, row = 0;
         bool lpt_on = false, live = false, ended = false, deferred = false;
-        uint32_t hm = NO_HIT, ev_next = 0;
-        V3 p = so, n = so, sd0 = so;
+        uint32_t hm = NO_HIT, hpc = NO_HIT, ev_next = 0;
+        V3 p = so, n = so, sd0 = so, ray_o = so;
+        float hit_t = 0.f;
         if (lane < take) {
           const uint32_t j = q0 + count + lane;  // pop: the top `take` entries
-          hm = SQ_LD_U(SQ_HITMAT, j);
+          hpc = SQ_LD_U(SQ_HITPC, j);
+          ray_o = mk(SQ_LD_F(SQ_O, j), SQ_LD_F(SQ_O + 1, j), SQ_LD_F(SQ_O + 2, j));
+          sd = mk(SQ_LD_F(SQ_D, j), SQ_LD_F(SQ_D + 1, j), SQ_LD_F(SQ_D + 2, j));
+          stime = SQ_LD_F(SQ_TIME, j);
+          hit_t = SQ_LD_F(SQ_T, j);
           // The texture value is fetched FIRST, while almost nothing of this pass is live: texture_eval
           // (Perlin turbulence / checker) is an out-of-line call and everything live across it adds to
           // the kernel's register count.
-          p = mk(SQ_LD_F(SQ_P, j), SQ_LD_F(SQ_P + 1, j), SQ_LD_F(SQ_P + 2, j));
           uint4 mlo = make_uint4(0, 0, 0, 0), mhi = make_uint4(0, 0, 0, 0);
           V3 texval = mk(0.f, 0.f, 0.f);
-          if (hm != NO_HIT) {
+          if (hpc != NO_HIT) {
+            rebuild_hit(hpc, ray_o, sd, stime, hit_t, p, n, hm);
             const uint32_t m_off = load_const(&lc->mat_lds);
             if (m_off) mlo = s_mem[(m_off >> 4) + 2u * hm], mhi = s_mem[(m_off >> 4) + 2u * hm + 1u];
             else mlo = sc.mat[2 * hm], mhi = sc.mat[2 * hm + 1];
             texval = material_texture<PASS_FEAT>(sc, mlo, mhi, p);  // = albedo / emission colour for constant textures
           }
-          sd = mk(SQ_LD_F(SQ_D, j), SQ_LD_F(SQ_D + 1, j), SQ_LD_F(SQ_D + 2, j));
-          stime = SQ_LD_F(SQ_TIME, j);
           strength = mk(SQ_LD_F(SQ_STRENGTH, j), SQ_LD_F(SQ_STRENGTH + 1, j), SQ_LD_F(SQ_STRENGTH + 2, j));
           bounces = SQ_LD_U(SQ_BOUNCES, j), s = SQ_LD_U(SQ_SAMPLE, j);
           RT_TL_BOUNCES(bounces);
@@ -393,8 +469,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           sd0 = sd;
           ended = true;
           V3 result = mk(0.f, 0.f, 0.f);
-          if (hm != NO_HIT) {
-            n = mk(SQ_LD_F(SQ_N, j), SQ_LD_F(SQ_N + 1, j), SQ_LD_F(SQ_N + 2, j));
+          if (hpc != NO_HIT) {
             const uint32_t kind = mhi.w & 0xffu;
             const float param = u2f(mlo.w);
             V3 emitted = mk(0.f, 0.f, 0.f);
@@ -502,9 +577,9 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         if (m_def != 0) {  // back onto the stack they came from, over entries this pass has consumed
           if (deferred) {
             const uint32_t i = q0 + count + lane_rank(m_def);
-            SQ_ST_U(SQ_HITMAT, i, hm);
-            SQ_ST_F(SQ_P, i, p.x), SQ_ST_F(SQ_P + 1, i, p.y), SQ_ST_F(SQ_P + 2, i, p.z);
-            SQ_ST_F(SQ_N, i, n.x), SQ_ST_F(SQ_N + 1, i, n.y), SQ_ST_F(SQ_N + 2, i, n.z);
+            SQ_ST_U(SQ_HITPC, i, hpc);
+            SQ_ST_F(SQ_T, i, hit_t);
+            SQ_ST_F(SQ_O, i, ray_o.x), SQ_ST_F(SQ_O + 1, i, ray_o.y), SQ_ST_F(SQ_O + 2, i, ray_o.z);
             SQ_ST_F(SQ_D, i, sd0.x), SQ_ST_F(SQ_D + 1, i, sd0.y), SQ_ST_F(SQ_D + 2, i, sd0.z);
             SQ_ST_F(SQ_TIME, i, stime);
             SQ_ST_U(SQ_EVDRAWS, i, ev_next);

@@ -69,6 +69,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   uint32_t n_box_it = 0, n_box_lanes = 0, n_slow_it = 0, n_slow_lanes = 0, n_shade = 0, n_shade_lanes = 0, n_refill = 0;
   unsigned long long t_shade = 0, t_box = 0, t_slow = 0, t_mark = 0;
 
+#define RT_DEFER_HIT 0  // this kernel keeps the hit record in registers from the hit to its SHADE phase
 #define RT_HOIST 0
 #define RT_REG_STACK0 0  // measured: six more live registers cost this kernel 7 % on sphere lists, Cornell's wrappers gain nothing
 #define RT_SAME_KIND_RUN 1  // consecutive SPHERE / RECT records in one go: simple_light (200 spheres) 16.0 -> 9.4 ms, Cornell 3.7 -> 3.6, smoke boxes 7.5 -> 7.15
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
 #undef RT_SAME_KIND_RUN
 #undef RT_REG_STACK0
 #undef RT_HOIST
+#undef RT_DEFER_HIT
 
   for (;;) {
     // ============================== SHADE / GEN (every lane, its own path) ==========================

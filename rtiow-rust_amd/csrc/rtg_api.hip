@@ -82,7 +82,8 @@ struct rtg_scene {
   uint32_t features = 0;
   uint32_t n_prog = 0, n_mat = 0, n_tex = 0;
   uint64_t bytes = 0;
-  void* buffers[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  void* buffers[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const uint32_t* d_parent = nullptr;  // buffers[8]: the wrapper around every program record (rt_pool_full.h rebuild_hit)
   hipStream_t own_stream = nullptr;  // rtg_par_cast_multi: this scene's launch stream (created on first use)
   int num_cus = 0;
   float* d_frame = nullptr;     // rtg_par_cast: device staging frame for host framebuffers
@@ -476,6 +477,20 @@ int rtg_scene_create(rtg_builder* b, const rtg_id* world, size_t n, int device, 
   s->dev.n_prog = s->n_prog;
   s->dev.n_mat = s->n_mat;
   for (const Packet& h : fs.hi) s->n_box += (h.w[3] & 0xffu) == OP_BOX ? 1u : 0u;
+  {  // the wrapper around every record (rt_pool_full.h rebuild_hit): PUSH / POP pairs nest in program order, boundary streams included
+    std::vector<uint32_t> parent(fs.hi.size(), 0xffffffffu), open;
+    for (size_t i = 0; i < fs.hi.size(); i++) {
+      const uint32_t op = fs.hi[i].w[3] & 0xffu;
+      if (op == OP_POP && !open.empty()) open.pop_back();
+      parent[i] = open.empty() ? 0xffffffffu : open.back();
+      if (op == OP_PUSH) open.push_back((uint32_t)i);
+    }
+    if ((rc = upload(&s->buffers[8], parent.data(), parent.size() * sizeof(uint32_t), &s->bytes))) {
+      rtg_scene_destroy(s);
+      return rc;
+    }
+    s->d_parent = (const uint32_t*)s->buffers[8];
+  }
   for (size_t i = 0; i < fs.hi.size(); i++)
     if ((fs.hi[i].w[3] & 0xffu) == OP_SEG) s->seg_first = (uint32_t)i + 1u, s->seg_end = fs.hi[i].w[2];
   if ((fs.features & (FEAT_ALL | FEAT_BOUNDARY)) == 0) {  // lean program (BOX / SPHERE / END): layout of its LDS image (rt_pool.h)
