@@ -524,6 +524,49 @@ int rto_debug_samples(rto_scene* s, const rto_camera* camera, const rto_params* 
   return 0;
 }
 
+// Traversal-order model (rto_scene.hpp OrderModel): renders the frame like rto_par_cast with the model switched on and returns one
+// row of 9 counters per Bvh root the rays met -- {leaves, calls, n_ref, p_ref, n_near, p_near, differ, below_entry, hits} -- in
+// `out` (room for `cap` rows); returns the number of rows, or a negative error.  The frame itself is discarded.
+int rto_debug_order_model(rto_scene* s, const rto_camera* camera, const rto_params* params, int threads, uint64_t* out, int cap) {
+  if (!s || !camera || !params || !out || cap <= 0) return fail(-1, "null argument");
+  const rto_params p = *params;
+  Camera cam = to_camera(camera);
+  int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+  if (nt < 1) nt = 1;
+  std::atomic<uint32_t> next_row{0};
+  std::vector<OrderModel> per_thread(nt);
+  auto work = [&](int tid) {
+    tl_order_model = &per_thread[tid];
+    for (;;) {
+      uint32_t row = next_row.fetch_add(1);
+      if (row >= p.ny) break;
+      uint32_t y = p.ny - 1 - row;
+      for (uint32_t x = 0; x < p.nx; x++)
+        if (owns(p, x, row)) (void)one_pixel(s->world, cam, p, x, y, nullptr);
+    }
+    tl_order_model = nullptr;
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nt; t++) pool.emplace_back(work, t);
+  work(0);
+  for (auto& t : pool) t.join();
+  OrderModel total;
+  for (auto& m : per_thread)
+    for (auto& r : m.rows)
+      if (r.root)
+        if (OrderModel::Row* d = total.row(r.root, r.leaves)) {
+          d->calls += r.calls, d->n_ref += r.n_ref, d->p_ref += r.p_ref, d->n_near += r.n_near, d->p_near += r.p_near;
+          d->differ += r.differ, d->below_entry += r.below_entry, d->hits += r.hits;
+        }
+  int n = 0;
+  for (auto& r : total.rows)
+    if (r.root && n < cap) {
+      uint64_t* o = out + 9 * n++;
+      o[0] = r.leaves, o[1] = r.calls, o[2] = r.n_ref, o[3] = r.p_ref, o[4] = r.n_near, o[5] = r.p_near, o[6] = r.differ, o[7] = r.below_entry, o[8] = r.hits;
+    }
+  return n;
+}
+
 int rto_debug_math(int /*device*/, int op, size_t n, const float* in, const float* in2, float* out) {
   for (size_t i = 0; i < n; i++) {
     float x = in[i];

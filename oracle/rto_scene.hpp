@@ -205,6 +205,8 @@ struct Object {
   virtual ~Object() = default;
   virtual bool hit(const Ray& ray, Range t_range, HitCtx& ctx, HitRecord* rec) const = 0;
   virtual Aabb bounding_box(Range exposure) const = 0;
+  // (traversal-order model below, not in the reference) does a ConstantMedium sit in this subtree? -- its `hit` draws from the RNG
+  virtual bool has_medium() const { return false; }
 };
 using ObjectPtr = std::shared_ptr<Object>;
 
@@ -283,6 +285,7 @@ struct FlipNormals final : Object {
     return true;
   }
   Aabb bounding_box(Range e) const override { return object->bounding_box(e); }
+  bool has_medium() const override { return object->has_medium(); }
 };
 
 // object.rs:262-292
@@ -300,6 +303,7 @@ struct Translate final : Object {
     Aabb b = object->bounding_box(e);
     return Aabb{b.min + offset, b.max + offset};
   }
+  bool has_medium() const override { return object->has_medium(); }
 };
 
 // object.rs:296-328
@@ -319,6 +323,7 @@ struct Scale final : Object {
     Aabb b = object->bounding_box(e);
     return Aabb{b.min * factor, b.max * factor};
   }
+  bool has_medium() const override { return object->has_medium(); }
 };
 
 // object.rs:335-390 (+ rotate_y :477-484)
@@ -347,6 +352,7 @@ struct RotateY final : Object {
     }
     return Aabb{mn, mx};
   }
+  bool has_medium() const override { return object->has_medium(); }
 };
 
 // object.rs:394-417
@@ -368,6 +374,7 @@ struct And final : Object {
     return false;
   }
   Aabb bounding_box(Range e) const override { return a->bounding_box(e).merge(b->bounding_box(e)); }
+  bool has_medium() const override { return a->has_medium() || b->has_medium(); }
 };
 
 // object.rs:489-528
@@ -385,6 +392,7 @@ struct LinearMove final : Object {
     Aabb t{bb.min + e.end * motion, bb.max + e.end * motion};
     return s.merge(t);
   }
+  bool has_medium() const override { return object->has_medium(); }
 };
 
 // object.rs:533-580
@@ -414,16 +422,48 @@ struct ConstantMedium final : Object {
     return false;
   }
   Aabb bounding_box(Range e) const override { return boundary->bounding_box(e); }
+  bool has_medium() const override { return true; }
 };
 
 // ------------------------------------------------------------------------------------------------
 // bvh.rs
 // ------------------------------------------------------------------------------------------------
+// Traversal-ORDER MODEL (not in the reference).  Counts what an order-dependent walk of the SAME tree would cost,
+// beside the reference's walk, without touching it: at every outermost call of Bvh::hit on a tree without a ConstantMedium the
+// model re-walks the tree NEAR CHILD FIRST -- the child on the side the ray comes from along the node's split axis (the axis
+// Bvh::new sorted on: left = the lower half, bvh.rs:51-72) -- with a tie-safe rule: a box is entered when min(best, far) >= start
+// and a hit replaces the best one when t < best, or t == best and its leaf comes earlier in the reference's depth-first order
+// (which is what `t < t_range.end`, object.rs:99, gives the reference).  Per root: calls, the reference's Aabb::hit / primitive
+// tests, the model's, results that differ from the reference's (t or leaf), and accepted hits with t below the entry distance of
+// their own leaf box (the roundoff cases in which a box test and a primitive test disagree: only there can the orders differ).
+struct OrderModel {
+  struct Row {
+    const void* root = nullptr;
+    uint64_t leaves = 0, calls = 0, n_ref = 0, p_ref = 0, n_near = 0, p_near = 0, differ = 0, below_entry = 0, hits = 0;
+  };
+  Row rows[8];
+  Row* row(const void* root, uint64_t leaves) {
+    for (auto& r : rows) {
+      if (r.root == root) return &r;
+      if (r.root == nullptr) {
+        r.root = root, r.leaves = leaves;
+        return &r;
+      }
+    }
+    return nullptr;
+  }
+};
+inline thread_local OrderModel* tl_order_model = nullptr;  // set by rto_debug_order_model around a render
+inline thread_local bool tl_order_model_busy = false;
+
 struct Bvh final : Object {
   Aabb bbox;
   size_t size = 0;
   std::unique_ptr<Bvh> left, right;  // BvhContents::Node
   ObjectPtr leaf;                    // BvhContents::Leaf
+  int axis = 0;                      // (order model) the axis this node's objects were sorted on
+  bool medium = false;               // (order model) a ConstantMedium below
+  bool has_medium() const override { return medium; }
 
   // Tie audit (tests/test_bvh_ties.py): what `sort_unstable_by` (bvh.rs:51) is free to do.  Counts the sorts whose keys
   // tie and those where a run of equal keys STRADDLES the median split (only there can the tie order change which leaf
@@ -496,8 +536,10 @@ struct Bvh final : Object {
       node->bbox = keyed[0].second->bounding_box(exposure);
       node->size = 1;
       node->leaf = keyed[0].second;
+      node->medium = node->leaf->has_medium();
       return node;
     }
+    node->axis = axis;
     size_t half = keyed.size() / 2;  // bvh.rs:68-72
     std::vector<ObjectPtr> l, r;
     for (size_t i = 0; i < keyed.size(); i++) (i < half ? l : r).push_back(keyed[i].second);
@@ -505,6 +547,7 @@ struct Bvh final : Object {
     node->left = build(std::move(l), exposure, audit);
     node->bbox = node->left->bbox.merge(node->right->bbox);
     node->size = node->left->size + node->right->size;
+    node->medium = node->left->medium || node->right->medium;
     return node;
   }
 
@@ -523,6 +566,7 @@ struct Bvh final : Object {
       node->bbox = objs[0]->bounding_box(exposure);
       node->size = 1;
       node->leaf = objs[0];
+      node->medium = node->leaf->has_medium();
       return node;
     }
     const size_t n = objs.size();
@@ -559,11 +603,94 @@ struct Bvh final : Object {
     node->left = build_sah(std::move(l), exposure);
     node->bbox = node->left->bbox.merge(node->right->bbox);
     node->size = node->left->size + node->right->size;
+    node->medium = node->left->medium || node->right->medium;
+    node->axis = best_axis;
     return node;
+  }
+
+  // ---- order model (see OrderModel) ----
+  struct ModelBest {
+    float t;
+    uint64_t leaf;  // index of the winning leaf in the reference's depth-first order
+    bool any;
+  };
+  void model_walk(const Ray& ray, float t_min, uint64_t first_leaf, ModelBest& best, OrderModel::Row& m) const {
+    m.n_near++;
+    // Aabb::hit's arithmetic (aabb.rs:16-27) with the tie-safe comparison
+    Vec3 inv_d(1.f / ray.direction.x, 1.f / ray.direction.y, 1.f / ray.direction.z);
+    Vec3 t0 = (bbox.min - ray.origin) * inv_d, t1 = (bbox.max - ray.origin) * inv_d;
+    Vec3 a(inv_d.x < 0.f ? t1.x : t0.x, inv_d.y < 0.f ? t1.y : t0.y, inv_d.z < 0.f ? t1.z : t0.z);
+    Vec3 b(inv_d.x < 0.f ? t0.x : t1.x, inv_d.y < 0.f ? t0.y : t1.y, inv_d.z < 0.f ? t0.z : t1.z);
+    const float start = rs_max(t_min, rs_max(rs_max(a.x, a.y), a.z));
+    const float end = rs_min(best.t, rs_min(rs_min(b.x, b.y), b.z));
+    if (!(best.any ? end >= start : end > start)) return;  // (nothing found yet: the range's end is exclusive, as in the reference)
+    if (leaf) {
+      Counters c;
+      HitCtx cx{nullptr, &c};
+      HitRecord r;
+      const float upto = (best.any && best.t < F32_MAX) ? std::nextafter(best.t, F32_MAX) : best.t;  // accepts t <= best once a hit is held
+      const bool h = leaf->hit(ray, Range{t_min, upto}, cx, &r);
+      m.p_near += c.prim_tests;
+      if (h && (r.t < best.t || (best.any && r.t == best.t && first_leaf < best.leaf))) {
+        if (r.t < start) m.below_entry++;
+        best.t = r.t, best.leaf = first_leaf, best.any = true;
+      }
+      return;
+    }
+    const float da = axis == 0 ? ray.direction.x : (axis == 1 ? ray.direction.y : ray.direction.z);
+    if (da < 0.f) {  // the ray comes from the upper side: right (upper half) first
+      right->model_walk(ray, t_min, first_leaf + left->size, best, m);
+      left->model_walk(ray, t_min, first_leaf, best, m);
+    } else {
+      left->model_walk(ray, t_min, first_leaf, best, m);
+      right->model_walk(ray, t_min, first_leaf + left->size, best, m);
+    }
+  }
+  // the reference's walk once more, only to learn WHICH leaf wins (same arithmetic as hit below)
+  bool ref_leaf(const Ray& ray, Range t_range, uint64_t first_leaf, float& t, uint64_t& which) const {
+    if (!bbox.hit(ray, t_range, nullptr)) return false;
+    if (leaf) {
+      HitCtx cx{nullptr, nullptr};
+      HitRecord r;
+      if (!leaf->hit(ray, t_range, cx, &r)) return false;
+      t = r.t, which = first_leaf;
+      return true;
+    }
+    float tl = 0.f, tr = 0.f;
+    uint64_t wl = 0, wr = 0;
+    const bool hl = left->ref_leaf(ray, t_range, first_leaf, tl, wl);
+    if (hl) t_range.end = tl;
+    const bool hr = right->ref_leaf(ray, t_range, first_leaf + left->size, tr, wr);
+    if (hl && hr) {
+      if (tl < tr) t = tl, which = wl;
+      else t = tr, which = wr;
+      return true;
+    }
+    if (hl) { t = tl, which = wl; return true; }
+    if (hr) { t = tr, which = wr; return true; }
+    return false;
   }
 
   // bvh.rs:84-120
   bool hit(const Ray& ray, Range t_range, HitCtx& ctx, HitRecord* rec) const override {
+    if (tl_order_model && !tl_order_model_busy && !medium) {
+      if (OrderModel::Row* m = tl_order_model->row(this, size)) {
+        tl_order_model_busy = true;
+        Counters c;
+        HitCtx cx{ctx.rng, &c};
+        const bool r = hit(ray, t_range, cx, rec);  // the reference's walk, counted
+        if (ctx.counters) ctx.counters->add(c);
+        m->calls++, m->n_ref += c.aabb_tests, m->p_ref += c.prim_tests, m->hits += r ? 1u : 0u;
+        ModelBest best{t_range.end, 0, false};
+        model_walk(ray, t_range.start, 0, best, *m);
+        float t_ref = 0.f;
+        uint64_t leaf_ref = 0;
+        const bool r2 = ref_leaf(ray, t_range, 0, t_ref, leaf_ref);
+        if (r2 != best.any || (r2 && (t_ref != best.t || leaf_ref != best.leaf))) m->differ++;
+        tl_order_model_busy = false;
+        return r;
+      }
+    }
     if (!bbox.hit(ray, t_range, ctx.counters)) return false;
     if (leaf) return leaf->hit(ray, t_range, ctx, rec);
     HitRecord hl, hr;
