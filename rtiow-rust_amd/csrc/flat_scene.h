@@ -37,7 +37,7 @@ enum Op : uint32_t {
   OP_RECT = 3,    // lo = (k, r0.start, r0.end, r1.start) hi = (r1.end, -, material, op|flags)
   OP_PUSH = 4,    // lo = (a, b, c, -)                   hi = (-, -, matching_pop, op|kind)
   OP_POP = 5,     // lo = (a, b, c, -)                   hi = (-, -, matching_push, op|kind)
-  OP_MEDIUM = 6,  // lo = (density, -, -, -)             hi = (end_pc, -, material, op|flags); boundary = records (pc, end_pc)
+  OP_MEDIUM = 6,  // lo = (density, 1 / density, -, -)   hi = (end_pc, -, material, op|flags); boundary = records (pc, end_pc)
   OP_PRISM = 7,   // lo = (p0.x, p1.x, p0.y, p1.y)       hi = (p0.z, p1.z, material, op|flags): rect_prism(p0, p1, material)
                   //      (object.rs:420-473), its six Rect::hit in the And-tree's order inside ONE instruction
   OP_BEND = 8,    // hi = (-, -, medium_pc, op): end of the record stream of a MEDIUM whose boundary is an object graph
@@ -56,6 +56,38 @@ enum Op : uint32_t {
                   // return t >= t_range.end; inside the And itself the later hit replaces, object.rs:403-409)
   OP_EXT = 12,    // data-only continuation of the record in front of it (a SPHERE with F_MOVE: lo = motion.xyz); never executed:
                   // the record that owns it steps over it
+  // Only in the SECOND program of a scene, the one the pool-2 kernel walks (rt_pool2.h; P2Table below):
+  OP_LIST = 13,   // hi = (first item, item count, -, op): commits the list-level items [first, first + count) of the P2Table, in
+                  //      order, from what was evaluated for them when the ray was created.  A W item is the last of its record.
+};
+
+// ---- the list level, hoisted (pool-2 kernel, rt_pool2.h) -------------------------------------------------------------------
+// A list world (lib.rs:33-49) tests EVERY top-level object for every ray, in order, against a shrinking t_range.end.  What a
+// top-level object contributes depends on the hits found before it only in a narrow way:
+//   a plain primitive (Sphere / Rect / rect_prism, fused wrappers included): through `t < t_range.end` (object.rs:99,195) -- a run of
+//     consecutive ones reduces to "its closest candidate, first wins, if closer than what was found before" (OP_SEG above);
+//   a ConstantMedium over ONE primitive: its two boundary queries run over f32::MIN..f32::MAX (object.rs:551-552), independent of
+//     the range; the range enters in `max(t1, start)`, `min(t2, end)` (:553-554) and decides whether the medium draws (:562);
+//   a wrapper around a Bvh (Translate{RotateY{Bvh}}, main.rs:295-316): whether the walk enters it is Aabb::hit of the Bvh's root
+//     box for the transformed ray -- start and far plane distances independent of the range, then `min(end, far) > start`.
+// So everything expensive at list level is evaluated when the ray is CREATED (shade / camera pass: 60 lanes wide, every lane on the
+// same record) into a per-path side record of two dwords per item, and the walk COMMITS a list-level run with one cheap record
+// (OP_LIST) that needs no company: the walk of the second program is Bvh streams and OP_LIST records only.  Items, in world order:
+enum P2Kind : uint32_t {
+  P2_NONE = 0,
+  P2_PRIMS = 1,   // a = first record, b = end record: a run of plain primitives (records behind the program's OP_END).  Side: (t, pc | face | textured)
+  P2_MEDIUM = 2,  // a = the MEDIUM record (its boundary primitive = a + 1).  Side: (t1, t2) of the two boundary queries, t1 = +inf: not crossed
+  P2_WRAPPED = 3, // a = the PUSH record, b = the wrapped Bvh's root BOX (= a + 1), c = first record behind the matching POP.  Side: (start, far)
+};
+struct P2Item {
+  uint32_t kind, a, b, c;
+};
+constexpr uint32_t P2_MAX_ITEMS = 5;  // side record = 2 x 5 dwords + ln of the first two draws of the event's stream (media, object.rs:562)
+constexpr uint32_t P2_MAX_MEDIA = 2;
+constexpr uint32_t F_P2_DEAD_POP = 1u << 12;  // POP (second program): no BOX or primitive record follows in the walk -- the ray need not be restored
+struct P2Table {
+  P2Item item[P2_MAX_ITEMS];
+  uint32_t n_items, n_media, n_wrapped, pad;
 };
 
 // flag bits in hi.w above the 8-bit opcode

@@ -298,6 +298,7 @@ struct LaunchConsts {
                                 // behind the hit's material index: from LDS it costs ~130 cycles instead of a trip to L2 (~1 500)
   uint32_t seg_first, seg_end;  // full-feature pool kernel: the records of the hoisted segment as program counters (flat_scene.h OP_SEG);
                                 // seg_end = 0: no segment, or hoisting switched off -- OP_SEG is then stepped over
+  uint32_t p2_lists;            // pool-2 kernel (rt_pool2.h): byte offset of the waves' id lists in LDS
 };
 typedef const __attribute__((address_space(4))) uint32_t* const_u32_ptr;
 template <typename T>

@@ -22,6 +22,7 @@
 #include "rt_pool.h"
 #include "rt_pool_full.h"
 #include "rt_sync_full.h"
+#include "rt_pool2.h"
 #include "rt_trace.h"
 #include "scene_builder.h"
 
@@ -82,7 +83,7 @@ struct rtg_scene {
   uint32_t features = 0;
   uint32_t n_prog = 0, n_mat = 0, n_tex = 0;
   uint64_t bytes = 0;
-  void* buffers[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  void* buffers[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   const uint32_t* d_parent = nullptr;  // buffers[8]: the wrapper around every program record (rt_pool_full.h rebuild_hit)
   hipStream_t own_stream = nullptr;  // rtg_par_cast_multi: this scene's launch stream (created on first use)
   int num_cus = 0;
@@ -116,6 +117,12 @@ struct rtg_scene {
   int hoist = 1;                            // full-feature pool kernel: evaluate the hoisted segment when a ray is created (flat_scene.h OP_SEG); 0 = the walk executes its records
   uint32_t seg_first = 0, seg_end = 0;      // ... its records, as record indices (0, 0: the program has none)
   int drain_share = 1;                      // pool kernels, drain-phase work sharing (rt_pool_full.h RT_DRAIN_SHARE): 0 = off
+  // The second program and its kernel (rt_pool2.h; flat_scene.h "the list level, hoisted"): n_prog2 = 0 when the world has another shape
+  int pool2 = 1;                            // 1 (default): programs with a second program run on the pool-2 kernel; 0: on the first full-feature kernel
+  uint32_t n_prog2 = 0, n_box2 = 0;
+  DevScene dev2{};                          // lo / hi = the second program (buffers[9], [10]); materials, textures, Perlin tables shared
+  const P2Table* d_p2 = nullptr;            // buffers[11]
+  Pool2Tuning pool2_tune{20, 16, 24, 8, 12, 16, 4};  // refill_min, box_leave, park_max, t_sphere, t_prism, t_list, t_push
   int small_frames = 1;                    // rtg_launch.inc pool_geometry: frames smaller than the chip get small workgroups and reservations
   LaunchCtx ctx[RTG_MAX_FRAMES];           // frames in flight
   int n_ctx = 1, next_ctx = 0;
@@ -493,6 +500,20 @@ int rtg_scene_create(rtg_builder* b, const rtg_id* world, size_t n, int device, 
   }
   for (size_t i = 0; i < fs.hi.size(); i++)
     if ((fs.hi[i].w[3] & 0xffu) == OP_SEG) s->seg_first = (uint32_t)i + 1u, s->seg_end = fs.hi[i].w[2];
+  if (!fs.hi2.empty()) {  // the second program (pool-2 kernel)
+    if ((rc = upload(&s->buffers[9], fs.lo2.data(), fs.lo2.size() * 16, &s->bytes)) ||
+        (rc = upload(&s->buffers[10], fs.hi2.data(), fs.hi2.size() * 16, &s->bytes)) ||
+        (rc = upload(&s->buffers[11], &fs.p2, sizeof(P2Table), &s->bytes))) {
+      rtg_scene_destroy(s);
+      return rc;
+    }
+    s->dev2 = s->dev;
+    s->dev2.lo = (const uint4*)s->buffers[9], s->dev2.hi = (const uint4*)s->buffers[10];
+    s->dev2.n_prog = s->n_prog2 = (uint32_t)fs.hi2.size();
+    s->dev2.lds_off = nullptr, s->dev2.lds_image_bytes = 0;
+    s->d_p2 = (const P2Table*)s->buffers[11];
+    for (const Packet& h : fs.hi2) s->n_box2 += (h.w[3] & 0xffu) == OP_BOX ? 1u : 0u;
+  }
   if ((fs.features & (FEAT_ALL | FEAT_BOUNDARY)) == 0) {  // lean program (BOX / SPHERE / END): layout of its LDS image (rt_pool.h)
     std::vector<uint32_t> ops(fs.hi.size()), off(fs.hi.size());
     for (size_t i = 0; i < fs.hi.size(); i++) ops[i] = fs.hi[i].w[3];
@@ -560,6 +581,7 @@ int rtg_scene_set_option(rtg_scene* s, const char* name, int value) {
   else if (k == "wg_per_cu") s->wg_per_cu = value;
   else if (k == "drain_share") s->drain_share = value;
   else if (k == "hoist") s->hoist = value;
+  else if (k == "pool2") s->pool2 = value;                      // 0: the first full-feature pool kernel also for programs the pool-2 kernel walks (A/B switch)
   else if (k == "deep_sized") s->deep_sized = value;
   else if (k == "mat_lds") s->mat_lds = value;
   else if (k == "small_frames") s->small_frames = value;        // 0: one geometry for every frame size (measurement switch)
@@ -571,6 +593,13 @@ int rtg_scene_set_option(rtg_scene* s, const char* name, int value) {
   else if (k == "run_ahead") s->pool_tune.run_ahead = s->full_tune.run_ahead = s->sync_tune.run_ahead = u;
   else if (k == "run_ahead_min") s->pool_tune.run_ahead_min = s->full_tune.run_ahead_min = s->sync_tune.run_ahead_min = u;
   else if (k == "sphere_min") s->pool_tune.sphere_min = s->full_tune.sphere_min = s->sync_tune.sphere_min = u;
+  else if (k == "p2_refill") s->pool2_tune.refill_min = u;      // pool-2 kernel's schedule thresholds (rt_pool2.h Pool2Tuning)
+  else if (k == "p2_box_leave") s->pool2_tune.box_leave = u;
+  else if (k == "p2_park") s->pool2_tune.park_max = u;
+  else if (k == "p2_sphere") s->pool2_tune.t_sphere = std::max(1u, u);
+  else if (k == "p2_prism") s->pool2_tune.t_prism = std::max(1u, u);
+  else if (k == "p2_list") s->pool2_tune.t_list = std::max(1u, u);
+  else if (k == "p2_push") s->pool2_tune.t_push = std::max(1u, u);
   else return fail(RTG_ERR_INVALID, "rtg_scene_set_option: unknown option '" + k + "'");
   return RTG_OK;
 }

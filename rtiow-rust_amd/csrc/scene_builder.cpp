@@ -406,7 +406,7 @@ void SceneBuilder::emit(uint32_t id, bool under_bvh, int depth, FlatScene* out, 
       {
         const size_t at = out->lo.size();
         const bool single = fuse_primitive(*this, o.a, out, false, false);  // (a moving boundary is an object graph: boundary_pair_t knows no time)
-        push(out, o.f[0], 0, 0, 0, 0, 0, o.mat,
+        push(out, o.f[0], 1.f / o.f[0], 0, 0, 0, 0, o.mat,  // (1 / density: object.rs:562's divide, done once -- the same correctly rounded f32 quotient)
              OP_MEDIUM | (under_bvh ? F_UNDER_BVH : 0u) | (single ? 0u : F_GENERAL_BOUNDARY) | mat_flags(*this, o.mat));
         // the boundary's own stream: evaluated twice per medium test by a nested walk (object.rs:551-552),
         // skipped by the main walk.  It starts a fresh wrapper depth (its rays are saved on a private stack).
@@ -483,6 +483,7 @@ void SceneBuilder::flatten(const uint32_t* world, size_t n, FlatScene* out) cons
   const bool full_pool = has_box && (out->features & (FEAT_XFORM | FEAT_MEDIUM | FEAT_RECT | FEAT_TEXTURE | FEAT_BOUNDARY)) != 0u &&
                          !(out->features & FEAT_DEEP);
   if (hoist_segments && full_pool && seg1 > seg0) flatten_program(world, n, out, seg0, seg1);
+  if (full_pool) (void)flatten_pool2(world, n, out);  // the second program, when the world has the shape for it
   if (out->features & FEAT_DEEP) {  // which instantiation of the general walk this graph needs (flat_scene.h)
     if (out->deep_wrappers <= DEEP_FEW_WRAPPERS) out->features |= FEAT_DEEP_FEW_WRAPPERS;
     if (out->deep_media <= 1) out->features |= FEAT_DEEP_ONE_LEVEL;
@@ -522,6 +523,120 @@ void SceneBuilder::flatten_program(const uint32_t* world, size_t n, FlatScene* o
   }
   close_run(out->lo.size());
   push(out, 0, 0, 0, 0, 0, 0, 0, OP_END);
+}
+
+// The second program (flat_scene.h "the list level, hoisted"; rt_pool2.h).  Every top-level object must be one of
+//   P  a plain primitive (one fused SPHERE / RECT / PRISM record),
+//   M  a ConstantMedium over one plain primitive (not moving),
+//   B  a Bvh whose leaves are all plain primitives,
+//   W  one wrapper level (what emit() turns into one PUSH / POP pair) around a B;
+// at most P2_MAX_ITEMS items (runs of P, M, W) and P2_MAX_MEDIA media, and at least one Bvh.  Layout: the WALK -- Bvh streams
+// (emit()'s own records), an OP_LIST record wherever list-level items stand between them, W as PUSH / stream / POP, OP_END -- then,
+// behind OP_END, the records of the P and M items for the evaluation at ray creation and for rebuild_hit.  Returns false (and
+// leaves lo2 / hi2 empty) for any other shape: the first program and the older kernels render it.
+bool SceneBuilder::flatten_pool2(const uint32_t* world, size_t n, FlatScene* out) const {
+  out->lo2.clear(), out->hi2.clear();
+  out->p2 = P2Table{};
+  auto bvh_of_plain = [&](uint32_t id) {
+    if (objects[id].kind != HostObject::BVH) return false;
+    std::vector<int32_t> todo(1, (int32_t)objects[id].a);
+    while (!todo.empty()) {
+      const HostBvhNode& nd = bvh_nodes[todo.back()];
+      todo.pop_back();
+      if (nd.leaf != kNone) {
+        if (!is_plain_primitive(*this, nd.leaf)) return false;
+      } else {
+        todo.push_back(nd.left), todo.push_back(nd.right);
+      }
+    }
+    return true;
+  };
+  auto classify = [&](uint32_t id) -> char {
+    const HostObject& o = objects[id];
+    if (is_plain_primitive(*this, id)) return 'P';
+    if (o.kind == HostObject::MEDIUM) return fuse_primitive(*this, o.a, nullptr, false, false) ? 'M' : 0;
+    if (bvh_of_plain(id)) return 'B';
+    if (o.kind == HostObject::TRANSLATE || o.kind == HostObject::ROTATE_Y || o.kind == HostObject::SCALE || o.kind == HostObject::MOVE ||
+        o.kind == HostObject::FLIP) {  // emit()'s generic wrapper: Translate{RotateY | LinearMove} is ONE level
+      const HostObject* w = &o;
+      if (o.kind == HostObject::TRANSLATE && (objects[o.a].kind == HostObject::ROTATE_Y || objects[o.a].kind == HostObject::MOVE)) w = &objects[o.a];
+      return bvh_of_plain(w->a) ? 'W' : 0;
+    }
+    return 0;
+  };
+  std::vector<char> cls(n);
+  bool any_bvh = false;
+  for (size_t i = 0; i < n; i++) {
+    cls[i] = classify(world[i]);
+    if (!cls[i]) return false;
+    any_bvh |= cls[i] == 'B' || cls[i] == 'W';
+  }
+  if (!any_bvh) return false;
+  FlatScene w;  // the walk, then the item records
+  P2Table t{};
+  struct Pending { size_t first_obj, end_obj; };  // P / M items wait for their records (emitted behind OP_END)
+  std::vector<std::pair<uint32_t, Pending>> pending;  // (item index, world objects)
+  auto new_item = [&](uint32_t kind) -> int {
+    if (t.n_items >= P2_MAX_ITEMS) return -1;
+    t.item[t.n_items].kind = kind;
+    return (int)t.n_items++;
+  };
+  uint32_t group_first = 0;  // first item of the list-level run that is being collected
+  auto close_group = [&]() {
+    if (t.n_items > group_first) push(&w, 0, 0, 0, 0, group_first, t.n_items - group_first, 0, OP_LIST);
+    group_first = t.n_items;
+  };
+  for (size_t i = 0; i < n;) {
+    if (cls[i] == 'P') {
+      size_t j = i;
+      while (j < n && cls[j] == 'P') j++;
+      const int it = new_item(P2_PRIMS);
+      if (it < 0) return false;
+      pending.push_back({(uint32_t)it, Pending{i, j}});
+      i = j;
+    } else if (cls[i] == 'M') {
+      const int it = new_item(P2_MEDIUM);
+      if (it < 0 || t.n_media >= P2_MAX_MEDIA) return false;
+      t.n_media++;
+      pending.push_back({(uint32_t)it, Pending{i, i + 1}});
+      i++;
+    } else if (cls[i] == 'B') {
+      close_group();
+      emit(world[i], false, 0, &w);
+      i++;
+    } else {  // W: its root test is the last item of the run in front of it
+      const int it = new_item(P2_WRAPPED);
+      if (it < 0) return false;
+      close_group();
+      const size_t at = w.lo.size();
+      emit(world[i], false, 0, &w);
+      if ((w.hi[at].w[3] & 0xffu) != OP_PUSH || (w.hi[at + 1].w[3] & 0xffu) != OP_BOX) return false;  // (cannot happen for a W)
+      t.item[it].a = (uint32_t)at, t.item[it].b = (uint32_t)at + 1u, t.item[it].c = (uint32_t)w.lo.size();
+      t.n_wrapped++;
+      i++;
+    }
+  }
+  close_group();
+  // a POP behind which the walk meets no BOX and no primitive any more need not restore the ray
+  {
+    bool ray_needed = false;
+    for (size_t r = w.lo.size(); r-- > 0;) {
+      const uint32_t op = w.hi[r].w[3] & 0xffu;
+      if (op == OP_POP && !ray_needed) w.hi[r].w[3] |= F_P2_DEAD_POP;
+      if (op != OP_POP && op != OP_LIST) ray_needed = true;
+    }
+  }
+  push(&w, 0, 0, 0, 0, 0, 0, 0, OP_END);
+  for (auto& pi : pending) {
+    P2Item& it = t.item[pi.first];
+    it.a = (uint32_t)w.lo.size();
+    for (size_t k = pi.second.first_obj; k < pi.second.end_obj; k++) emit(world[k], false, 0, &w);
+    it.b = (uint32_t)w.lo.size();
+  }
+  if (w.features & (FEAT_DEEP | FEAT_BOUNDARY)) return false;
+  out->lo2 = std::move(w.lo), out->hi2 = std::move(w.hi);
+  out->p2 = t;
+  return true;
 }
 
 void SceneBuilder::finish_materials(FlatScene* out) const {

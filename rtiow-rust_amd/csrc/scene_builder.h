@@ -56,6 +56,9 @@ struct FlatScene {
   bool has_perlin = false;
   int deep_wrappers = 0;  // most wrappers (PUSH) open at once in any one stream of the program
   int deep_media = 0;     // deepest level of boundary queries a walk of the program recurses into (0 = no object-graph boundary)
+  // the SECOND program (flat_scene.h "the list level, hoisted"): empty unless the world has the shape the pool-2 kernel walks
+  std::vector<Packet> lo2, hi2;
+  P2Table p2{};
 };
 
 class SceneBuilder {
@@ -84,6 +87,7 @@ class SceneBuilder {
   void emit_bvh(int32_t node, int depth, FlatScene* out, int boundary, bool mark_roots, int saves) const;
   bool holds_medium(uint32_t obj) const;
   void flatten_program(const uint32_t* world, size_t n, FlatScene* out, size_t seg0, size_t seg1) const;
+  bool flatten_pool2(const uint32_t* world, size_t n, FlatScene* out) const;
   void finish_materials(FlatScene* out) const;
 };
 
