@@ -219,6 +219,13 @@ int rtg_debug_math(int device, int op, size_t n, const float* in, const float* i
 int rtg_debug_flatten(rtg_builder* b, const rtg_id* world, size_t n, uint32_t* n_instructions,
                       uint32_t* features, uint32_t* words_out, size_t capacity_instructions);
 
+/* Host-only: the SECOND flat program of `world` -- the one the pool-2 kernel walks (csrc/flat_scene.h "the list level,
+ * hoisted": Bvh streams and OP_LIST records, then the records of the list-level items) -- and its item table: 4 words
+ * (kind, a, b, c) per item, P2_MAX_ITEMS = 5 items, then (n_items, n_media, n_wrapped, 0): 24 words in `table_out`.
+ * *n_instructions = 0 when the world has another shape (such worlds render on the first program only). */
+int rtg_debug_flatten_pool2(rtg_builder* b, const rtg_id* world, size_t n, uint32_t* n_instructions, uint32_t* table_out,
+                            uint32_t* words_out, size_t capacity_instructions);
+
 #ifdef __cplusplus
 }
 #endif

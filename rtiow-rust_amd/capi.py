@@ -77,7 +77,7 @@ ABI_SYMBOLS = [
     "material_isotropic", "object_sphere", "object_rect", "object_flip_normals", "object_translate",
     "object_scale", "object_rotate_y", "object_and", "object_rect_prism", "object_linear_move",
     "object_constant_medium", "object_bvh", "object_bvh_sah", "camera_look", "scene_create", "scene_destroy",
-    "scene_set_option", "scene_info", "par_cast", "par_cast_device", "par_cast_multi", "multi_reset", "debug_hit_top", "debug_samples", "debug_math", "debug_flatten", "tonemap", "tonemap_device",
+    "scene_set_option", "scene_info", "par_cast", "par_cast_device", "par_cast_multi", "multi_reset", "debug_hit_top", "debug_samples", "debug_math", "debug_flatten", "debug_flatten_pool2", "tonemap", "tonemap_device",
 ]
 
 
@@ -139,6 +139,7 @@ class Backend:
                                       C.POINTER(Stats)])
         f("multi_reset", C.c_int, [C.c_char_p, C.POINTER(C.c_uint64)])
         f("debug_flatten", C.c_int, [C.c_void_p, c_u32p, C.c_size_t, c_u32p, c_u32p, c_u32p, C.c_size_t])
+        f("debug_flatten_pool2", C.c_int, [C.c_void_p, c_u32p, C.c_size_t, c_u32p, c_u32p, c_u32p, C.c_size_t])
         f("tonemap_device", C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p])
 
     def _fn(self, name, restype, argtypes):
@@ -319,6 +320,19 @@ class Builder:
         self.be.check(self.be._debug_flatten(self.h, arr, len(world), C.byref(n), C.byref(feat),
                                              words.ctypes.data_as(c_u32p), n.value))
         return words, feat.value
+
+    def flatten_pool2(self, world):
+        """The second flat program (pool-2 kernel) and its item table: (words [n, 8], items [(kind, a, b, c)], n_media, n_wrapped);
+        words has 0 rows when the world has another shape."""
+        arr = (C.c_uint32 * max(1, len(world)))(*world)
+        n = C.c_uint32()
+        table = np.zeros(24, dtype=np.uint32)
+        self.be.check(self.be._debug_flatten_pool2(self.h, arr, len(world), C.byref(n), table.ctypes.data_as(c_u32p), None, 0))
+        words = np.zeros((n.value, 8), dtype=np.uint32)
+        self.be.check(self.be._debug_flatten_pool2(self.h, arr, len(world), C.byref(n), table.ctypes.data_as(c_u32p),
+                                                   words.ctypes.data_as(c_u32p), n.value))
+        items = [tuple(int(v) for v in table[4 * k:4 * k + 4]) for k in range(int(table[20]))]
+        return words, items, int(table[21]), int(table[22])
 
     def bvh_sah(self, objs, exposure=(0.0, 1.0)):
         """Not in the reference: SAH-built Bvh; same results up to exact-t ties, fewer box tests."""

@@ -23,6 +23,12 @@
 
 namespace rtg {
 
+#ifndef RT_P2_EXP
+#define RT_P2_EXP 0  // cost probes (WRONG pictures): bit 0 / 1 / 2 / 3 = hoist_eval without its primitive runs / media / wrapped Bvhs / random words
+#endif
+#ifndef RT_P2_RELOAD_SIDE
+#define RT_P2_RELOAD_SIDE 0  // 1: every lane re-reads its side record from the slot after a service (12 registers dead across the passes: 117 -> 107 VGPRs, and 1 % slower)
+#endif
 #ifndef RT_P2_POOL
 #define RT_P2_POOL 224  // paths in flight per wave (64 in the lanes + the ones that wait for company in S, X, E and T)
 #endif
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         const uint32_t q_end = __builtin_amdgcn_readfirstlane(s_table[4u * k + 2u]) * RSZ;
         float c_t = F32_MAX;
         uint32_t c_pc = 0u;
-        for (uint32_t q = ia; q < q_end;) {
+        for (uint32_t q = ia; q < q_end && !(RT_P2_EXP & 1);) {
           float t;
           uint32_t tag, q_next;
           if (prim_test(std::true_type{}, q, ro, rd, rtime, c_t, t, tag, n_prim, q_next)) c_t = t, c_pc = q | tag;
@@ -213,12 +219,12 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         const uint4 blo = P2_LO(ia + RSZ), bhi = P2_HI(ia + RSZ);
         float t1 = 0.f, t2 = 0.f;
         uint32_t n_tests;
-        const bool crossed = boundary_pair_t(blo, bhi, ro, rd, t1, t2, n_tests);
+        const bool crossed = (RT_P2_EXP & 2) ? (n_tests = 0, false) : boundary_pair_t(blo, bhi, ro, rd, t1, t2, n_tests);
         n_prim += n_tests;
         SL_ST_SIDE(id, k, f2u(crossed ? t1 : P2_NOT_CROSSED), f2u(t2));
       } else {  // P2_WRAPPED: the wrapper's PUSH on a copy of the ray, then Aabb::hit's two distances for the Bvh's root box (aabb.rs:16-27)
         V3 to = ro, td = rd;
-        push_xform(P2_LO(ia), P2_HI(ia), rtime, to, td);
+        if (!(RT_P2_EXP & 4)) push_xform(P2_LO(ia), P2_HI(ia), rtime, to, td);
         const V3 ti = mk(1.f / td.x, 1.f / td.y, 1.f / td.z);
         const uint4 b_lo = P2_LO(ia + RSZ), b_hi = P2_HI(ia + RSZ);
         const float t0x = (u2f(b_lo.x) - to.x) * ti.x, t1x = (u2f(b_lo.y) - to.x) * ti.x;
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         SL_ST_SIDE(id, k, f2u(start), f2u(far));
       }
     }
-    if (__builtin_amdgcn_readfirstlane(s_table[4u * P2_MAX_ITEMS + 1u]) != 0u) {  // media: draws 0 and 1 of the ray's event (object.rs:562)
+    if (!(RT_P2_EXP & 8) && __builtin_amdgcn_readfirstlane(s_table[4u * P2_MAX_ITEMS + 1u]) != 0u) {  // media: draws 0 and 1 of the ray's event (object.rs:562)
       SampleRng r;
       r.init(seed, pixel, sample);
       r.set_event(event);
@@ -434,6 +440,11 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
             SL_ST1(id, PS_BOUNCES, bounces);
             SL_ST3(id, PS_STRENGTH, f2u(strength.x), f2u(strength.y), f2u(strength.z));
             uint32_t h_aabb, h_prim;
+            if (RT_P2_EXP & 16) {
+              V3 p2_ = p;
+              asm volatile("" : "+v"(p2_.x));
+              hoist_eval(id, p2_, nd, stime, seed, pixel, s, bounces + 1u, h_aabb, h_prim);
+            }
             hoist_eval(id, p, nd, stime, seed, pixel, s, bounces + 1u, h_aabb, h_prim);
             if (COUNT) cnt.aabb += h_aabb, cnt.prim += h_prim, cnt.rays++;
             if (COUNT && tr_slot) tr_slot[P2POOL + id] += h_aabb, tr_slot[2u * P2POOL + id] += h_prim;
@@ -622,7 +633,9 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
             my_slot = te[t_count - 1u - r];
             const p2_u32x4 a0 = SL_LD4(my_slot, PS_O);
             const p2_u32x3 a1 = SL_LD3(my_slot, PS_D);
+#if !RT_P2_RELOAD_SIDE
             sdA = SL_LD4(my_slot, PS_SIDE), sdB = SL_LD4(my_slot, PS_SIDE + 16u), sdC = SL_LD4(my_slot, PS_SIDE + 32u);
+#endif
             o = mk(u2f(a0.x), u2f(a0.y), u2f(a0.z)), time = u2f(a0.w);
             d = mk(u2f(a1.x), u2f(a1.y), u2f(a1.z));
             pc = 0, best = F32_MAX, hmat = NO_HIT, ev = 0;
@@ -634,6 +647,10 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         }
       }
       // 1/d and the current record of EVERY lane are (re)derived here, so that these registers are dead across the passes above
+#if RT_P2_RELOAD_SIDE
+      // ... and so is the side record: every lane that holds a ray reads it (again) from its slot -- 12 registers that the passes need
+      sdA = SL_LD4(my_slot, PS_SIDE), sdB = SL_LD4(my_slot, PS_SIDE + 16u), sdC = SL_LD4(my_slot, PS_SIDE + 32u);
+#endif
       inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
       cur_lo = P2_LO(pc), cur_hi = P2_HI(pc);
       if (COUNT) t_refill += RT_TICK() - t_mark2;

@@ -122,7 +122,7 @@ struct rtg_scene {
   uint32_t n_prog2 = 0, n_box2 = 0;
   DevScene dev2{};                          // lo / hi = the second program (buffers[9], [10]); materials, textures, Perlin tables shared
   const P2Table* d_p2 = nullptr;            // buffers[11]
-  Pool2Tuning pool2_tune{20, 16, 24, 8, 12, 16, 4};  // refill_min, box_leave, park_max, t_sphere, t_prism, t_list, t_push
+  Pool2Tuning pool2_tune{24, 48, 40, 4, 8, 24, 2};  // refill_min, box_leave, park_max, t_sphere, t_prism, t_list, t_push
   int small_frames = 1;                    // rtg_launch.inc pool_geometry: frames smaller than the chip get small workgroups and reservations
   LaunchCtx ctx[RTG_MAX_FRAMES];           // frames in flight
   int n_ctx = 1, next_ctx = 0;

@@ -192,4 +192,13 @@ extern "C" {
         words_out: *mut u32,
         capacity_instructions: usize,
     ) -> c_int;
+    pub fn rtg_debug_flatten_pool2(
+        b: *mut rtg_builder,
+        world: *const rtg_id,
+        n: usize,
+        n_instructions: *mut u32,
+        table_out: *mut u32,
+        words_out: *mut u32,
+        capacity_instructions: usize,
+    ) -> c_int;
 }

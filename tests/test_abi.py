@@ -58,7 +58,7 @@ def test_rust_sys_crate_declares_every_header_symbol():
 
 def test_oracle_mirrors_the_abi(pkg, oracle):
     for s in pkg.capi.ABI_SYMBOLS:
-        if s in ("device_count", "scene_set_option", "scene_info", "par_cast_device", "debug_flatten", "tonemap_device", "multi_reset"):
+        if s in ("device_count", "scene_set_option", "scene_info", "par_cast_device", "debug_flatten", "debug_flatten_pool2", "tonemap_device", "multi_reset"):
             continue  # device plumbing has no CPU counterpart
         assert hasattr(oracle.lib, "rto_" + s), s
 

@@ -61,10 +61,12 @@ def test_fuzz_graphs_bit_exact(pkg, gpu, oracle, seed):
     img_o, st_o = so.par_cast(cam_o, nx, ny, ns, stats=True)
     # a frame this small is routed to the lock-step kernel by default (rtg_launch.inc: tiny frames): both schedules, explicitly
     # (programs the pool kernels do not take -- lean ones, FEAT_DEEP -- ignore the option)
-    for sync in (0, 1):
+    # (pool2 = 2: graphs with a second program -- flat_scene.h "the list level, hoisted" -- also on the pool-2 kernel at this size)
+    for sync, pool2 in ((0, 0), (0, 2), (1, 0)):
         sg.set_option("sync", sync)
+        sg.set_option("pool2", pool2)
         img_g, st_g = sg.par_cast(cam_g, nx, ny, ns, stats=True)
-        assert_bit_equal(img_g, img_o, "fuzz scene %d sync=%d" % (seed, sync))
+        assert_bit_equal(img_g, img_o, "fuzz scene %d sync=%d pool2=%d" % (seed, sync, pool2))
         for k in ("aabb_tests", "prim_tests", "shaded_hits", "rays", "draws"):
             assert st_g[k] == st_o[k], (seed, sync, k, st_g[k], st_o[k])
         # ... and the timed instantiation of the same kernel (no counters: other register allocation, other spills)

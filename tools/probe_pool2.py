@@ -36,7 +36,7 @@ for name, keep in VARIANTS:
     sc = b.scene([world[i] for i in keep])
     res = {}
     for v in (0, 1):
-        sc.set_option("pool2", v)
+        sc.set_option("pool2", 2 * v)
         sc.par_cast(cam, nx, ny, 1)
         if "--verbose" in sys.argv:
             print("-- %s, pool2 = %d" % (name, v), file=sys.stderr, flush=True)
@@ -49,7 +49,7 @@ for name, keep in VARIANTS:
     ts = {0: [], 1: []}
     for _ in range(4):
         for v in (0, 1):
-            sc.set_option("pool2", v)
+            sc.set_option("pool2", 2 * v)
             t0 = time.perf_counter()
             sc.par_cast(cam, nx, ny, ns)
             ts[v].append(time.perf_counter() - t0)
