@@ -88,6 +88,11 @@ def cpu_baseline(pkg, build_scene, nx, ny, target_seconds=12.0, max_spp=1000):
                     "(same row granularity as lib.rs:326-330) on the cores the cgroup quota allows"}
 
 
+def rank_px_big(samples):
+    """rtg_launch.inc: programs with a second flat program (book-2) take the pool-2 kernel from 32 M samples per launch on."""
+    return samples >= (32 << 20) and os.environ.get("RTG_POOL2", "1") != "0"
+
+
 def self_launch(n, backend):
     """`python bench.py --gpus N` without a launcher: run this file as N ranks under torch.distributed.run (one rank per
     GPU, rendezvous on 127.0.0.1) and pass the JSON line and the exit code through.  Refuses, non-zero, when the host has
@@ -275,6 +280,7 @@ def main():
                    and (nx, ny) == (wnx, wny))
     if default_run and not args.no_also:
         from rtiow_rust_amd import roofline as rl_a
+        valu_costs, _ = rl_a.load_valu_costs(ROOT)
 
         def anchor(wl, a_spp, a_steps, profile_key=None, bvh="reference"):
             a_build, anx, any_, _, _, _ = WORKLOADS[wl]
@@ -286,6 +292,9 @@ def main():
             a_fb = torch.zeros((any_, anx, 3), dtype=torch.float32, device=dev)
             a_p = pkg.make_params(anx, any_, a_spp, seed=args.seed)
             one = lambda: a_scene.par_cast_device(a_cam, a_p, ctypes.c_void_p(a_fb.data_ptr()), stream, want_stats=True)  # noqa: E731
+            # counting pass (untimed, instrumented variant): N / P / H of this frame for roofline.algorithmic_valu
+            a_pc = pkg.make_params(anx, any_, a_spp, seed=args.seed, flags=pkg.capi.FLAG_COUNTERS)
+            a_cst = a_scene.par_cast_device(a_cam, a_pc, ctypes.c_void_p(a_fb.data_ptr()), stream, want_stats=True)
             one()
             torch.cuda.synchronize()
             a_t0 = time.perf_counter()
@@ -294,6 +303,7 @@ def main():
             a_dt = (time.perf_counter() - a_t0) / a_steps
             res = {"value": anx * any_ * a_spp / a_dt / 1e6, "unit": "Msamples/s", "ms_per_step": a_dt * 1e3,
                    "kernel_ms_avg": sum(k_ms) / len(k_ms), "steps": a_steps, "warmup": 1}
+            a_alg = rl_a.algorithmic_valu(valu_costs, a_cst, anx * any_ * a_spp, sum(k_ms) / len(k_ms) * 1e-3, root=ROOT)
             if profile_key:
                 # the same object as the headline's, from the counters collected AT this config (profiles/current.json
                 # "<workload>@<spp>"), under the same staleness rule: another build -> frac null + the reason
@@ -309,6 +319,12 @@ def main():
                         res["roofline"]["stale_profile"] = r["stale_profile"]
                 else:
                     res["roofline"] = {"bound": "valu", "frac": None, "traffic": None, "pmc_source": None}
+            else:
+                res["roofline"] = {"bound": "valu", "frac": None, "traffic": None, "pmc_source": None}
+            # today's `frac` counts every issued instruction: also reported under its plain name; the fraction of USEFUL work beside it
+            res["roofline"]["valu_lane_utilisation"] = res["roofline"].get("frac")
+            res["roofline"]["algorithmic_valu"] = a_alg
+            res["roofline"]["counters_per_launch"] = {k: a_cst[k] for k in ("aabb_tests", "prim_tests", "shaded_hits", "rays", "draws")}
             return res
         also = {"book1_random_spheres_1200x800x500spp": dict(anchor("book1", 500, 5, "book1"), baseline_config="configs[2] on ONE GPU (north_star target frame)"),
                 "book2_final_scene_800x800x1000spp": dict(anchor("book2", 1000, 3, "book2"), baseline_config="configs[3]"),
@@ -328,7 +344,9 @@ def main():
         # events on the launch stream; peak = 256 CUs x 4 SIMDs x shader clock / issue cycles per wave64 instruction.
         # tools/roofline.py recomputes the same object from profiles/<tag>/pmc_summary.json + kernel_stats.csv.
         from rtiow_rust_amd import roofline as rl
-        kernel_name = {"book1": "rtg::render_lean_pool", "book2": "rtg::render_full_pool", "cornell": "rtg::render_full_sync"}[args.workload]
+        # (book-2: frames of >= 32 M samples run on the pool-2 kernel, smaller ones on the first full-feature kernel: rtg_launch.inc)
+        kernel_name = {"book1": "rtg::render_lean_pool", "book2": "rtg::render_full_pool2" if rank_px_big(px_rank * spp) else "rtg::render_full_pool",
+                       "cornell": "rtg::render_full_sync"}[args.workload]
         kernel_s = avg_kernel_ms * 1e-3
         rank_samples = px_rank * spp
         pmc, pmc_path = rl.find_profile(ROOT, (args.workload if args.bvh == "reference" else args.workload + "_" + args.bvh) + ("_bvh4" if args.bvh4 else ""), spp, frame=(nx, ny))
@@ -346,6 +364,10 @@ def main():
         else:   # no counter profile for this workload: the contract's keys with the unmeasured ones null
             roof = {"bound": "valu", "achieved": None, "peak": rl.N_CUS * rl.SIMDS_PER_CU * 64 * rl.NOMINAL_CLOCK_HZ / rl.ISSUE_CYCLES / 1e9,
                     "unit": "G lane-instructions/s", "frac": None, "traffic": None}
+        # `frac` credits every issued instruction (services, list bookkeeping, spill code): kept, and named for what it is;
+        # `algorithmic_valu` prices the reference's own work only (roofline.py algorithmic_valu, tools/algorithmic_valu.py)
+        roof["valu_lane_utilisation"] = roof.get("frac")
+        roof["algorithmic_valu"] = rl.algorithmic_valu(rl.load_valu_costs(ROOT)[0], cst, rank_samples, kernel_s, root=ROOT)
         roof.update({
             "kernel": kernel_name + " (+ rtg::fold_samples_kernel, ~1%): HIP events around both on the launch stream",
             "kernel_ms_avg": avg_kernel_ms,

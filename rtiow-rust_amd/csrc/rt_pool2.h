@@ -26,6 +26,9 @@ namespace rtg {
 #ifndef RT_P2_EXP
 #define RT_P2_EXP 0  // cost probes (WRONG pictures): bit 0 / 1 / 2 / 3 = hoist_eval without its primitive runs / media / wrapped Bvhs / random words
 #endif
+#ifndef RT_P2_PREFETCH
+#define RT_P2_PREFETCH 0  // 1: a finishing lane asks for its slot's line again so that the pass that takes the slot next finds it in the L2 -- measured 3 % SLOWER (r06d)
+#endif
 #ifndef RT_P2_RELOAD_SIDE
 #define RT_P2_RELOAD_SIDE 0  // 1: every lane re-reads its side record from the slot after a service (12 registers dead across the passes: 117 -> 107 VGPRs, and 1 % slower)
 #endif
@@ -141,6 +144,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   uint32_t pc = 0, hmat = NO_HIT, ev = 0;
   uint4 cur_lo = make_uint4(0, 0, 0, 0), cur_hi = make_uint4(0, 0, 0, OP_END);
   p2_u32x4 sdA = {0, 0, 0, 0}, sdB = sdA, sdC = sdA;  // the side record: items 0-1, 2-3, 4 + (ln u0, ln u1)
+  [[maybe_unused]] uint32_t prefetch_sink = 0;  // (keeps the prefetch loads alive: stored at the end under a condition that never holds)
   Counts cnt = {0, 0, 0, 0};
   uint32_t total_draws = 0;
   uint32_t* tr_out = nullptr;   // per-sample trace (instrumented variant; rt_pool.h): counters[30] = the table, counters[31] = per-slot accumulators
@@ -319,6 +323,11 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         const bool to_s = fin && !to_e && !to_x;
         const uint64_t m_e = __builtin_amdgcn_ballot_w64(to_e), m_x = __builtin_amdgcn_ballot_w64(to_x), m_s = __builtin_amdgcn_ballot_w64(to_s);
         if (fin) {
+#if RT_P2_PREFETCH
+          // the pass that takes this slot next reads its whole line, which has left the L2 since the refill (the working set of an XCD's
+          // waves is ~14 MB): ask for it now -- one dword, nobody waits for it -- so that the line is back when the pass starts
+          prefetch_sink ^= SL_LD1(my_slot, to_e ? PS_SAMPLE : PS_O);
+#endif
           if (!to_e) SL_ST3(my_slot, PS_BEST, f2u(best), hmat, ev);
           if (COUNT && tr_slot) tr_slot[my_slot] += ev, tr_slot[P2POOL + my_slot] += cnt.aabb - tr_a0, tr_slot[2u * P2POOL + my_slot] += cnt.prim - tr_p0;
           if (to_e) te[P2POOL - 1u - (e_count + lane_rank(m_e))] = (uint16_t)(my_slot | E_MISS);
@@ -845,6 +854,9 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
       if (64u - busy >= tune.refill_min || busy == 0) break;
     }
   }
+#if RT_P2_PREFETCH
+  if (prefetch_sink == 0x9e3779b9u && total_work == 0xffffffffu) counters[63] = prefetch_sink;
+#endif
   if (COUNT) {
     atomicAdd(&counters[0], (unsigned long long)cnt.aabb);
     atomicAdd(&counters[1], (unsigned long long)cnt.prim);

@@ -123,6 +123,52 @@ def valu_roofline(pmc, kernel_s, samples=None, clock_hz=None, issue_cycles=None,
     return out
 
 
+def load_valu_costs(root):
+    """The per-operation VALU costs tools/algorithmic_valu.py read from the production kernels' ISA (profiles/current.json
+    "valu_costs"), with the same build-stamp rule as the counter profiles.  Returns (dict or None, path or None)."""
+    idx = os.path.join(root, "profiles", "current.json")
+    try:
+        rel = json.load(open(idx)).get("valu_costs")
+        if not rel:
+            return None, None
+        return json.load(open(os.path.join(root, rel))), rel
+    except Exception:
+        return None, None
+
+
+def algorithmic_valu(costs, counters, samples, kernel_s, root=None, clock_hz=None, issue_cycles=None):
+    """VALU lane-instructions of the REFERENCE's own work per launch / kernel seconds / the f32 lane peak:
+
+        lanes = c_box * N + c_prim * P + c_shade * H + c_cam * samples
+
+    N / P / H = Aabb::hit calls, primitive tests and shaded hits of the reference walk (the oracle's counters, SURVEY.md 8d; the
+    instrumented kernel's are tested equal to them at the named sizes), c_* = VALU instructions per lane and operation in the ISA
+    of the lean production kernel (tools/algorithmic_valu.py: static counts, loops once -- a lower bound).  ONE set of costs prices
+    every workload, whichever kernel renders it: the cheapest implementation of each reference operation the build has, so the
+    figure falls when a kernel spends instructions on anything else (services, list bookkeeping, spill code, work done twice)
+    and rises only when the same reference work takes less time."""
+    clock = clock_hz or NOMINAL_CLOCK_HZ
+    peak = N_CUS * SIMDS_PER_CU * 64 * clock / (issue_cycles or ISSUE_CYCLES)
+    out = {"unit": "G lane-instructions/s", "peak": peak / 1e9, "achieved": None, "frac": None,
+           "definition": "(c_box*aabb_tests + c_prim*prim_tests + c_shade*shaded_hits + c_cam*samples) / kernel seconds / "
+                         "(256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / 2 cycles per wave64 instruction)"}
+    if not costs:
+        out["stale_costs"] = "no cost file (tools/algorithmic_valu.py)"
+        return out
+    if root is not None:
+        st = costs.get("build", {})
+        now = source_stamp(root)
+        if st.get("digest") != now["digest"]:
+            out["stale_costs"] = "kernel sources changed since tools/algorithmic_valu.py read the ISA"
+            return out
+    k = costs["kernels"]["render_lean_pool"]
+    c = {n: k["c_" + n] for n in ("box", "prim", "shade", "cam")}
+    lanes = c["box"] * counters["aabb_tests"] + c["prim"] * counters["prim_tests"] + c["shade"] * counters["shaded_hits"] + c["cam"] * samples
+    out.update({"c_box": c["box"], "c_prim": c["prim"], "c_shade": c["shade"], "c_cam": c["cam"], "costs_from": k["kernel"],
+                "lane_instructions_per_launch": lanes, "achieved": lanes / kernel_s / 1e9, "frac": lanes / kernel_s / peak})
+    return out
+
+
 def find_profile(root, workload_key, spp=None, frame=None):
     """profiles/current.json maps a workload key ("book1", "book2", "cornell", "<workload>@<spp>" for counters collected
     at another named config: "book1@500" = C3's frame, "book2@1000" = C4 -- and "<workload>@<spp>@<nx>x<ny>" for another frame

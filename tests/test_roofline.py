@@ -53,3 +53,35 @@ def test_current_profiles_belong_to_this_build(pkg):
             stale[k] = why
     if stale:
         pytest.skip("stale counter profiles (re-run tools/collect_profiles.sh): %s" % stale)
+
+
+def test_algorithmic_valu_prices_reference_work_only(pkg):
+    """roofline.algorithmic_valu: c_box N + c_prim P + c_shade H + c_cam samples over the f32 lane peak; costs of
+    another build are refused like counters of another build."""
+    from rtiow_rust_amd import roofline as rl
+    costs = {"kernels": {"render_lean_pool": {"kernel": "k", "c_box": 20.0, "c_prim": 50.0, "c_shade": 300.0, "c_cam": 100.0}}, "build": rl.source_stamp(ROOT)}
+    cnt = {"aabb_tests": 1000, "prim_tests": 100, "shaded_hits": 10, "rays": 12, "draws": 99}
+    a = rl.algorithmic_valu(costs, cnt, 5, 1e-6, root=ROOT)
+    lanes = 20.0 * 1000 + 50.0 * 100 + 300.0 * 10 + 100.0 * 5
+    assert a["lane_instructions_per_launch"] == lanes and abs(a["achieved"] - lanes / 1e-6 / 1e9) < 1e-9
+    assert abs(a["peak"] - 256 * 4 * 64 * 2.4e9 / 2 / 1e9) < 1e-6 and abs(a["frac"] - a["achieved"] / a["peak"]) < 1e-12
+    # twice the time, half the fraction; more overhead instructions change nothing (they are not in the formula)
+    assert abs(rl.algorithmic_valu(costs, cnt, 5, 2e-6, root=ROOT)["frac"] - a["frac"] / 2) < 1e-12
+    costs["build"]["digest"] = "0" * 40
+    stale = rl.algorithmic_valu(costs, cnt, 5, 1e-6, root=ROOT)
+    assert stale["frac"] is None and "stale_costs" in stale
+    assert rl.algorithmic_valu(None, cnt, 5, 1e-6)["frac"] is None
+
+
+def test_committed_valu_costs_have_the_four_operations(pkg):
+    import json
+    from rtiow_rust_amd import roofline as rl
+    costs, rel = rl.load_valu_costs(ROOT)
+    if costs is None:
+        import pytest
+        pytest.skip("no valu_costs entry in profiles/current.json yet")
+    for kern in ("render_lean_pool", "render_full_pool", "render_full_pool2"):
+        k = costs["kernels"][kern]
+        assert 15 <= k["c_box"] <= 40 and 30 <= k["c_prim"] <= 150 and 200 <= k["c_shade"] <= 2000 and 100 <= k["c_cam"] <= 2000, (kern, k)
+        for r in k["regions"].values():
+            assert r["lines"][0] <= r["lines"][1] and r["valu"] <= r["instructions"]

@@ -5,25 +5,23 @@
 # C1 (Cornell).  profiles/current.json then maps "<workload>[@<spp>[@<nx>x<ny>]]" to the pmc_summary.json of that launch.
 tag=$1; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O
 cd $R
-LEAN="render_lean_pool<true, false"; FULL="render_full_pool<1, true, false"
+LEAN="render_lean_pool<true, false"; FULL="render_full_pool<1, true, false"; FULL2="render_full_pool2<true, false"  # (book-2 frames of >= 32 M samples: the pool-2 kernel)
 PROFILE_FRAME="1200 800 50"  tools/profile_kernel.sh ${tag}_book1 book1 "$LEAN" 48000000 > $O/profile_book1.log 2>&1
 PROFILE_FRAME="1200 800 500" tools/profile_kernel.sh ${tag}_book1_c3 book1 "$LEAN" 480000000 --spp 500 > $O/profile_book1_c3.log 2>&1
-PROFILE_FRAME="800 800 100"  tools/profile_kernel.sh ${tag}_book2 book2 "$FULL" 64000000 --spp 100 > $O/profile_book2.log 2>&1
-PROFILE_FRAME="800 800 1000" tools/profile_kernel.sh ${tag}_book2_c4 book2 "$FULL" 640000000 > $O/profile_book2_c4.log 2>&1
+PROFILE_FRAME="800 800 100"  tools/profile_kernel.sh ${tag}_book2 book2 "$FULL2" 64000000 --spp 100 > $O/profile_book2.log 2>&1
+PROFILE_FRAME="800 800 1000" tools/profile_kernel.sh ${tag}_book2_c4 book2 "$FULL2" 640000000 > $O/profile_book2_c4.log 2>&1
 PROFILE_FRAME="300 300 100"  tools/profile_kernel.sh ${tag}_book2_readme book2 "$FULL" 9000000 --nx 300 --ny 300 --spp 100 > $O/profile_book2_readme.log 2>&1
 PROFILE_FRAME="300 300 100"  tools/profile_kernel.sh ${tag}_cornell cornell "render_full_sync<1, false, false" 9000000 > $O/profile_cornell.log 2>&1
 for k in book1 book1_c3 book2 book2_c4 book2_readme cornell; do mkdir -p $O/$k; cp gpurun_out/${tag}_$k/* $O/$k/; done
 # the bench lines below take their instruction counts from THIS build's counters (bench.py reads profiles/current.json)
-cat > profiles/current.json <<EOT
-{
- "book1": "gpurun_out/$tag/book1/pmc_summary.json",
- "book1@500": "gpurun_out/$tag/book1_c3/pmc_summary.json",
- "book2": "gpurun_out/$tag/book2/pmc_summary.json",
- "book2@1000": "gpurun_out/$tag/book2_c4/pmc_summary.json",
- "book2@100@300x300": "gpurun_out/$tag/book2_readme/pmc_summary.json",
- "cornell": "gpurun_out/$tag/cornell/pmc_summary.json"
-}
-EOT
+python3 - $tag <<'PY'
+import json, sys
+tag = sys.argv[1]
+cur = json.load(open("profiles/current.json"))
+for key, d in (("book1", "book1"), ("book1@500", "book1_c3"), ("book2", "book2"), ("book2@1000", "book2_c4"), ("book2@100@300x300", "book2_readme"), ("cornell", "cornell")):
+    cur[key] = "gpurun_out/%s/%s/pmc_summary.json" % (tag, d)
+json.dump(cur, open("profiles/current.json", "w"), indent=1)   # ("valu_costs": tools/algorithmic_valu.py's file, made where hipcc is -- kept)
+PY
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --spp 500 --no-cpu-baseline > $O/bench_500spp.json 2>/dev/null
 python bench.py --bvh sah --no-cpu-baseline > $O/bench_sah.json 2>/dev/null
@@ -41,6 +39,9 @@ python tools/criterion_scene.py > $O/criterion_scene.txt 2>&1
 python tools/latency_probe.py > $O/latency_probe.txt 2>&1
 python tools/shard_time.py > $O/shard_time.txt 2>&1
 python tools/probe_book2_levers.py > $O/book2_levers.txt 2>&1
+python tools/probe_pool2.py 800 800 100 > $O/pool_vs_pool2.txt 2>&1
+python tools/probe_pool2.py 800 800 1000 --only all >> $O/pool_vs_pool2.txt 2>&1
+RTG_POOL2=0 python tools/tail_probe.py book2 800 800 > $O/tail_probe_book2_first_kernel.txt 2>&1
 python tools/time_deep_fuzz.py > $O/deep_fuzz.txt 2>&1
 python -m pytest tests -m gpu -q --timeout=300 > $O/pytest_gpu.log 2>&1
 ls -la $O

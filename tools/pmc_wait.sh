@@ -13,7 +13,7 @@ cd $R
 python3 - $O <<'PY'
 import csv, glob, sys, collections
 O = sys.argv[1]
-for kern in ("render_lean_pool<true, false", "render_full_pool<1, true, false", "render_full_sync<1, false, false"):
+for kern in ("render_lean_pool<true, false", "render_full_pool<1, true, false", "render_full_pool2<true, false", "render_full_sync<1, false, false"):
     c = collections.defaultdict(lambda: collections.defaultdict(float))
     for f in glob.glob(O + '/raw*/**/*_counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):

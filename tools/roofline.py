@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Recompute bench.py's `roofline` object from committed profile files alone.
 
-usage: tools/roofline.py profiles/<tag>/pmc_summary.json profiles/<tag>/kernel_stats.csv [kernel_substr]
+usage: tools/roofline.py profiles/<tag>/pmc_summary.json profiles/<tag>/kernel_stats.csv [kernel_substr [bench.json [anchor]]]
+
+With a bench line (profiles/<round>/bench*.json) the `algorithmic_valu` object is recomputed too: the reference work counters of
+that line (`roofline.counters_per_launch`, or those of `also.<anchor>`) priced with profiles/<round>/algorithmic_valu_costs.json (next
+to the bench line, else profiles/current.json "valu_costs") over the kernel time of kernel_stats.csv.
 
 kernel time = the AverageNs of the timed render kernel in rocprofv3's --kernel-trace --stats summary (un-profiled
 by counters); instruction counts, lane utilisation, LDS duty and HBM bytes from the PMC passes of the same command.
@@ -32,6 +36,13 @@ def main():
         raise SystemExit("kernel %r not in %s" % (want, stats_path))
     roof = rl.valu_roofline(pmc, ns * 1e-9)
     roof["kernel_ms_avg"] = ns * 1e-6
+    if len(sys.argv) > 4:
+        line = json.load(open(sys.argv[4]))
+        r = line["also"][sys.argv[5]]["roofline"] if len(sys.argv) > 5 else line["roofline"]
+        local = os.path.join(os.path.dirname(os.path.abspath(sys.argv[4])), "algorithmic_valu_costs.json")
+        costs = json.load(open(local)) if os.path.exists(local) else rl.load_valu_costs(ROOT)[0]
+        roof["valu_lane_utilisation"] = roof.get("frac")
+        roof["algorithmic_valu"] = rl.algorithmic_valu(costs, r["counters_per_launch"], pmc["samples_per_launch"], ns * 1e-9)
     print(json.dumps(roof, indent=1))
 
 
