@@ -135,6 +135,9 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: 'strong' (default) shards the workload's FIXED multi-GPU frame (book1: 500 spp = C3, "
                          "book2: 5000 spp = C5); 'weak' renders N x the N = 1 spp (per-GPU samples fixed)")
+    ap.add_argument("--reduce-mode", choices=["reduce", "gather"], default="reduce",
+                    help="N > 1: 'reduce' (default) = ONE RCCL reduce(sum) of the zero-padded float3 framebuffer to rank 0, as north_star "
+                         "names it; 'gather' = ONE gather of the ranks' packed tiles (1 / N of the bytes per rank), bit-identical by construction")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xDEADBEEF)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true",
@@ -204,7 +207,7 @@ def main():
     info_lean = args.workload == "book1"
 
     from rtiow_rust_amd import parallel   # the ONE sharding implementation (also what tests/test_dist_cpu.py drives)
-    frame = parallel.ShardedFrame(nx, ny, dev, via_host=(backend != "nccl"))
+    frame = parallel.ShardedFrame(nx, ny, dev, via_host=(backend != "nccl"), mode=args.reduce_mode)
     fb = frame.fb
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -217,7 +220,8 @@ def main():
         if world == 1:
             return frame.render(render_shard)
         # the same three steps as ShardedFrame.render (zero, this rank's tiles, ONE reduce(sum) to rank 0), with events round the reduce
-        frame.fb.zero_()
+        if frame.mode == "reduce":
+            frame.fb.zero_()
         out = render_shard(frame.fb, frame.rank, frame.world)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -381,7 +385,8 @@ def main():
             shard_txt = "none"
         elif args.scaling == "strong" or args.spp:
             shard_txt = ("the FIXED %dx%dx%d frame, interleaved %dx%d pixel tiles (tile %% %d == rank): strong scaling; ONE RCCL "
-                         "reduce(sum) of the float3 framebuffer to rank 0 per frame" % (nx, ny, spp, frame.tile[0], frame.tile[1], world))
+                         "%s to rank 0 per frame" % (nx, ny, spp, frame.tile[0], frame.tile[1], world,
+                                                     "reduce(sum) of the float3 framebuffer" if frame.mode == "reduce" else "gather of the ranks' packed tiles"))
         else:
             shard_txt = ("interleaved %dx%d pixel tiles (tile %% %d == rank), spp = %d*N: weak scaling; ONE RCCL reduce(sum) "
                          "of the float3 framebuffer to rank 0 per frame" % (frame.tile[0], frame.tile[1], world, wspp))
@@ -412,6 +417,8 @@ def main():
             line["per_rank"] = per_rank
             # rank 0 receives the frame: its reduce time with the slowest rank's kernel taken out is the transfer itself
             line["reduce_ms_avg"] = per_rank[0]["reduce_ms_avg"]
+            line["reduce_mode"] = frame.mode                      # "reduce": full frames summed; "gather": packed tiles collected
+            line["reduce_bytes_per_rank"] = frame.bytes_per_rank()
             line["slowest_rank_kernel_ms"] = max(r["kernel_ms_avg"] for r in per_rank)
         if also is not None:
             line["also"] = also

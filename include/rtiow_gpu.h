@@ -174,7 +174,10 @@ int rtg_par_cast_device(rtg_scene* s, const rtg_camera* camera, const rtg_params
  * RCCL / xGMI (librccl is dlopen()ed on first use with > 1 distinct device), assembles the frame: x + 0 is exact, the
  * result is bit-identical to rtg_par_cast on one GPU.  Scenes that share a device are summed on that device first.
  * params->rank / nranks must be 0 / 0-or-1 (the call shards by itself).  out_rgb: caller-owned HOST memory.
- * stats: kernel_ms = the slowest shard, counters summed over the shards.  Synchronous. */
+ * stats: kernel_ms = the slowest shard, counters summed over the shards.  Synchronous.
+ * Scene option "multi_gather" = 1 (on any handle) selects the PACKED collective instead: every scene packs the pixels it owns
+ * (1 / n_scenes of the frame), grouped ncclSend / ncclRecv bring the packed tiles of the other devices to the first one, which
+ * scatters them into its frame -- copies only, bit-identical by construction, 1 / n_scenes of the bytes per device. */
 int rtg_par_cast_multi(rtg_scene* const* scenes, int n_scenes, const rtg_camera* camera,
                        const rtg_params* params, float* out_rgb, rtg_stats* stats_or_null);
 

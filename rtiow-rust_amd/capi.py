@@ -369,7 +369,7 @@ class Scene:
     # measurement / test hook: RTG_<OPTION>=<int> in the environment of the PYTHON process becomes
     # rtg_scene_set_option(scene, "<option>", <int>) -- the library itself reads no environment variable
     ENV_OPTIONS = ("kernel", "chunks", "lpt", "lpt_phase1", "lpt_deep", "lpt_shift", "ray_lds", "sync", "block", "wg_per_cu", "window",
-                   "box_leave", "refill_min", "gather_min", "run_ahead", "run_ahead_min", "sphere_min", "verbose", "bvh4", "force_rccl", "scratch_mb", "frames_in_flight", "small_frames", "drain_share", "hoist", "deep_sized", "mat_lds", "pool2", "p2_refill", "p2_box_leave", "p2_park", "p2_sphere", "p2_prism", "p2_list", "p2_push")
+                   "box_leave", "refill_min", "gather_min", "run_ahead", "run_ahead_min", "sphere_min", "verbose", "bvh4", "force_rccl", "multi_gather", "scratch_mb", "frames_in_flight", "small_frames", "drain_share", "hoist", "deep_sized", "mat_lds", "pool2", "p2_refill", "p2_box_leave", "p2_park", "p2_sphere", "p2_prism", "p2_list", "p2_push")
 
     def set_option(self, name, value):
         self.be.check(self.be._scene_set_option(self.h, name.encode(), int(value)))

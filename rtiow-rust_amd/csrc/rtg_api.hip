@@ -96,6 +96,11 @@ struct rtg_scene {
   int window = -1;             // full-feature kernel: records of the program staged in LDS (-1 = as many as fit)
   int ray_lds = 1;             // 0: all slot fields in global memory
   int force_rccl = 0;          // rtg_par_cast_multi: run the RCCL reduce even over ONE distinct device (a clique of one)
+  int multi_gather = 0;        // rtg_par_cast_multi: 1 = the packed collective (every scene ships its own tiles only; rtg_multi.inc) instead of the full-frame reduce
+  float* d_pack = nullptr;     // ... this scene's tiles, packed in work-item order (on its device)
+  size_t pack_bytes = 0;
+  float* d_recv = nullptr;     // ... and where they arrive on the first device
+  size_t recv_bytes = 0;
   int bvh4 = 0;                // 1: traverse the 4-wide collapse of the Bvh (same image, other counters; needs wide_bytes)
   uint32_t wide_bytes = 0;     // size of the 4-wide image in buffers[7], 0 = the scene has none
   int sync_full = -1;          // full-feature scenes on the pool-free lock-step kernel (rt_sync_full.h): -1 = when the program holds no BOX record, 0 / 1 = never / always
@@ -442,6 +447,8 @@ void rtg_scene_destroy(rtg_scene* s) {
     if (c.done) (void)hipEventDestroy(c.done);
   }
   if (s->d_frame) (void)hipFree(s->d_frame);
+  if (s->d_pack) (void)hipFree(s->d_pack);
+  if (s->d_recv) (void)hipFree(s->d_recv);
   if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
   delete s;
 }
@@ -573,6 +580,7 @@ int rtg_scene_set_option(rtg_scene* s, const char* name, int value) {
     s->n_ctx = value, s->next_ctx = 0;
   }
   else if (k == "force_rccl") s->force_rccl = value;
+  else if (k == "multi_gather") s->multi_gather = value;        // rtg_par_cast_multi: the packed collective (1 / n of the bytes per scene) instead of the reduce
   else if (k == "sync") s->sync_full = value;
   else if (k == "block") {
     if (value < 64 || value > 1024 || value % 64) return fail(RTG_ERR_INVALID, "block: a multiple of 64 in [64, 1024]");

@@ -23,14 +23,22 @@ scene, cam, nx, ny, ns = build_case(pkg, ora, "book1", 64, 48)
 def render_shard(fb, rank, world):
     part = scene.par_cast(cam, nx, ny, ns, rank=rank, nranks=world, threads=2)
     fb.copy_(torch.from_numpy(part))
-frame = parallel.render_sharded(render_shard, nx, ny, torch.device("cpu"))
+frame = parallel.render_sharded(render_shard, nx, ny, torch.device("cpu"), mode=sys.argv[2])
 if rank == 0:
     np.save(sys.argv[1], frame.numpy())
+    sf = parallel.ShardedFrame(nx, ny, torch.device("cpu"), mode=sys.argv[2])
+    assert sf.bytes_per_rank() == (nx * ny * 12 if sys.argv[2] == "reduce" else max(sf.owned_pixels(r).numel() for r in range(world)) * 12)
+    assert sum(sf.owned_pixels(r).numel() for r in range(world)) == nx * ny
 dist.barrier(); dist.destroy_process_group()
 '''
 
 
-def test_two_rank_gloo_reduce_equals_single_frame(tmp_path, pkg, oracle):
+import pytest
+
+
+@pytest.mark.parametrize("mode", ["reduce", "gather"])
+def test_two_rank_gloo_reduce_equals_single_frame(tmp_path, pkg, oracle, mode):
+    """mode "reduce": ONE reduce(sum) of zero-padded full frames; "gather": ONE gather of the ranks' packed tiles (1 / world of the bytes)."""
     from conftest import assert_bit_equal
     from scene_cases import build_case
     out = str(tmp_path / "frame.npy")
@@ -40,14 +48,14 @@ def test_two_rank_gloo_reduce_equals_single_frame(tmp_path, pkg, oracle):
 
     def run(port):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
-        procs = [subprocess.Popen([sys.executable, str(script), out], env=dict(env, RANK=str(r)), stderr=subprocess.PIPE, text=True)
+        procs = [subprocess.Popen([sys.executable, str(script), out, mode], env=dict(env, RANK=str(r)), stderr=subprocess.PIPE, text=True)
                  for r in range(2)]
         errs = [p.communicate(timeout=300)[1] for p in procs]
         return max(abs(p.returncode) for p in procs), "\n".join(errs)
     rc, err = retry_on_busy_port(run)
     assert rc == 0, err[-2000:]
     scene, cam, nx, ny, ns = build_case(pkg, oracle, "book1", 64, 48)
-    assert_bit_equal(np.load(out), scene.par_cast(cam, nx, ny, ns), "2-rank sharded frame")
+    assert_bit_equal(np.load(out), scene.par_cast(cam, nx, ny, ns), "2-rank sharded frame, %s" % mode)
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus():

@@ -229,6 +229,45 @@ def test_par_cast_multi_through_the_real_rccl_symbols(pkg, gpu, oracle):
     assert gpu.multi_reset() == (1 if n_dev < 2 else 2)
 
 
+@pytest.mark.timeout(300)
+def test_par_cast_multi_packed_collective(pkg, gpu, oracle):
+    """Scene option multi_gather = 1: every handle ships only the tiles it owns (packed in work-item order) and the first device
+    scatters them into the frame -- grouped ncclSend / ncclRecv instead of the full-frame ncclReduce.  Copies only: the frame is the
+    oracle's bit for bit with 1, 2, 3 and 8 handles, ragged sizes and both tile sizes; with force_rccl the first handle's tiles take
+    the send / recv path on this one-GPU box too (a clique of one), and rtg_multi_reset counts the transfers."""
+    for name, nx, ny, ns in (("book1", 176, 112, 6), ("book2", 100, 76, 4)):
+        so, cam_o, _, _, _ = build_case(pkg, oracle, name, nx, ny)
+        ref, st_o = so.par_cast(cam_o, nx, ny, ns, stats=True)
+        for n in (1, 2, 3, 8):
+            scenes = []
+            for _ in range(n):
+                sg, cam_g, _, _, _ = build_case(pkg, gpu, name, nx, ny)
+                sg.set_option("multi_gather", 1)
+                scenes.append(sg)
+            img, st = gpu.par_cast_multi(scenes, cam_g, nx, ny, ns, stats=True)
+            assert_bit_equal(img, ref, "%s, %d handles, packed" % (name, n))
+            for k in ("samples", "aabb_tests", "prim_tests", "shaded_hits", "rays", "draws"):
+                assert st[k] == st_o[k], (name, n, k)
+            assert_bit_equal(gpu.par_cast_multi(scenes, cam_g, nx, ny, ns, tile_w=8, tile_h=8), ref, "%s, %d handles, packed, 8x8 tiles" % (name, n))
+    n_dev = gpu.device_count()
+    gpu.multi_reset()
+    nx, ny, ns = 96, 64, 6
+    so, cam_o, _, _, _ = build_case(pkg, oracle, "book1", nx, ny)
+    ref = so.par_cast(cam_o, nx, ny, ns)
+    for n in (1, 3):
+        scenes = []
+        for i in range(n):
+            b = gpu.builder()
+            world, cam_g, _ = pkg.scenes.random_scene(b, nx, ny)
+            sg = b.scene(world, device=i % min(n_dev, 2))
+            sg.set_option("force_rccl", 1)
+            sg.set_option("multi_gather", 1)
+            scenes.append(sg)
+        assert_bit_equal(gpu.par_cast_multi(scenes, cam_g, nx, ny, ns), ref, "force_rccl + packed, %d handles" % n)
+    issued = gpu.multi_reset()
+    assert issued == (2 if n_dev < 2 else 1 + 1), issued   # one transfer per handle that travels (one GPU: the first handle, to itself)
+
+
 @pytest.mark.parametrize("name,nx,ny,ns,mb", [("cornell", 300, 300, 400, 16), ("book1", 300, 300, 400, 16), ("book2", 160, 160, 60, 1),
                                                ("book1", 200, 120, 37, 1)])
 def test_bounded_sample_scratch_renders_in_passes(pkg, gpu, oracle, name, nx, ny, ns, mb, capfd):
@@ -491,8 +530,8 @@ def test_scene_reuse_across_sizes_and_sample_counts(pkg, gpu, oracle):
         assert_bit_equal(sg.par_cast(cg, nx, ny, ns), so.par_cast(cg, nx, ny, ns), "%dx%dx%d" % (nx, ny, ns))
 
 
-@pytest.mark.parametrize("scaling", ["strong", "weak"])
-def test_bench_multi_rank_path_on_one_gpu(tmp_path, scaling):
+@pytest.mark.parametrize("scaling,mode", [("strong", "reduce"), ("weak", "reduce"), ("strong", "gather")])
+def test_bench_multi_rank_path_on_one_gpu(tmp_path, scaling, mode):
     """bench.py's N>1 leg (tile sharding by rank through rtiow_rust_amd.parallel.ShardedFrame + framebuffer reduce +
     max-over-ranks timing), run as 2 ranks that share the single GPU of this box (RTG_BENCH_BACKEND=gloo test hook:
     RCCL refuses two ranks per device).  --verify makes rank 0 compare the reduced frame with an unsharded render.
@@ -509,7 +548,7 @@ def test_bench_multi_rank_path_on_one_gpu(tmp_path, scaling):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
                "--gpus", "2", "--steps", "2", "--warmup", "1", "--nx", "320", "--ny", "192", "--verify", "--no-cpu-baseline",
-               "--scaling", scaling]
+               "--scaling", scaling, "--reduce-mode", mode]
         runs.append(subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600))
         return runs[-1].returncode, runs[-1].stderr
     retry_on_busy_port(run)
@@ -526,6 +565,8 @@ def test_bench_multi_rank_path_on_one_gpu(tmp_path, scaling):
     assert all(r["kernel_ms_avg"] > 0 and r["reduce_ms_avg"] >= 0 and r["samples"] > 0 for r in line["per_rank"])
     assert sum(r["samples"] for r in line["per_rank"]) == 320 * 192 * (500 if scaling == "strong" else 100)
     assert line["reduce_ms_avg"] == line["per_rank"][0]["reduce_ms_avg"]
+    # which collective assembled the frame, and what a rank handed to it: the whole zero-padded frame, or its own tiles only
+    assert line["reduce_mode"] == mode and line["reduce_bytes_per_rank"] == (320 * 192 * 12 if mode == "reduce" else 320 * 192 * 12 // 2)
     assert line["slowest_rank_kernel_ms"] == max(r["kernel_ms_avg"] for r in line["per_rank"]) <= line["ms_per_step"] * 1.05
 
 
