@@ -630,7 +630,7 @@ RT_DEV bool hit_top(const DevScene& sc, V3 o, V3 d, float time, float t_near, Sa
       pc = hi.x;  // first record after the boundary's stream
       continue;
     }
-    pc++;  // unreachable for well-formed programs
+    pc++;  // OP_SEG: this interpreter hoists nothing -- it steps over the record and executes the segment's primitives (flat_scene.h)
   }
   return any;
 }

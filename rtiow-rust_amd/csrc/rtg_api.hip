@@ -186,7 +186,7 @@ struct DevBuf {
 
 extern "C" {
 
-const char* rtg_version(void) { return "rtiow-rust_amd 0.1 (gfx950 HIP; flat-program ray-pool kernels)"; }
+const char* rtg_version(void) { return "rtiow-rust_amd 0.2 (gfx950 HIP; flat-program ray-pool kernels; flat-program encoding 3: OP_SEG = 9, OP_SAVE / OP_MERGE / OP_EXT = 10 / 11 / 12, OP_LIST = 13, MEDIUM lo.y = 1 / density)"; }
 const char* rtg_last_error(void) { return g_err.c_str(); }
 
 int rtg_device_count(int* n) {

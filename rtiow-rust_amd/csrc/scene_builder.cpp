@@ -497,21 +497,20 @@ void SceneBuilder::flatten_program(const uint32_t* world, size_t n, FlatScene* o
   out->features = 0;
   out->deep_wrappers = 0, out->deep_media = 0;
   // Runs of consecutive list-level objects that hold no Bvh are straight-line code every ray executes in
-  // the same order: their first record is marked F_GATHER so a scheduler can batch the rays there.  (The records of a hoisted
-  // segment do not count: a kernel that commits the segment at its OP_SEG record never executes them.)
-  size_t run_start = 0, run_skipped = 0;
+  // the same order: their first record is marked F_GATHER so a scheduler can batch the rays there.
+  size_t run_start = 0;
   bool in_run = false;
   auto close_run = [&](size_t end) {
-    if (in_run && end - run_start - run_skipped >= 4) out->hi[run_start].w[3] |= F_GATHER;
-    in_run = false, run_skipped = 0;
+    // (the FULL run counts, the records of a hoisted segment included: the lock-step kernel, the baseline kernel and the pool kernel
+    // with hoisting switched off execute them)
+    if (in_run && end - run_start >= 4) out->hi[run_start].w[3] |= F_GATHER;
+    in_run = false;
   };
   size_t seg_at = 0;
   for (size_t i = 0; i < n; i++) {
     const size_t at = out->lo.size();
     if (seg1 > seg0 && i == seg0) seg_at = at, push(out, 0, 0, 0, 0, 0, 0, 0, OP_SEG);
-    const size_t first = out->lo.size();
     emit(world[i], false, 0, out);
-    if (seg1 > seg0 && i >= seg0 && i < seg1) run_skipped += out->lo.size() - first;
     if (seg1 > seg0 && i + 1 == seg1) out->hi[seg_at].w[2] = (uint32_t)out->lo.size();
     bool has_box = false;
     for (size_t r = at; r < out->lo.size(); r++) has_box |= (out->hi[r].w[3] & 0xffu) == OP_BOX;

@@ -193,6 +193,24 @@ def test_pool2_schedule_switches_never_change_a_bit(pkg, gpu, oracle, opts):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("hoist,mat_lds", [(0, 1), (1, 0), (0, 0)])
+def test_first_kernel_switches_hoist_and_mat_lds(pkg, gpu, oracle, hoist, mat_lds):
+    """The FIRST full-feature pool kernel with its hoisted segment (OP_SEG) and its LDS material records switched off, one at a time
+    and together: the same bits and the same counters as the oracle (ADVICE r5 #1)."""
+    nx, ny, ns = 96, 72, 6
+    so, cam_o, _, _, _ = build_case(pkg, oracle, "book2", nx, ny)
+    img_o, st_o = so.par_cast(cam_o, nx, ny, ns, stats=True)
+    sg, cam_g, _, _, _ = build_case(pkg, gpu, "book2", nx, ny)
+    for k, v in (("sync", 0), ("pool2", 0), ("hoist", hoist), ("mat_lds", mat_lds)):
+        sg.set_option(k, v)
+    img_g, st_g = sg.par_cast(cam_g, nx, ny, ns, stats=True)
+    assert_bit_equal(img_g, img_o, "hoist=%d mat_lds=%d" % (hoist, mat_lds))
+    for k in KEYS:
+        assert st_g[k] == st_o[k], (hoist, mat_lds, k)
+    assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns), img_o, "hoist=%d mat_lds=%d (timed variant)" % (hoist, mat_lds))
+
+
+@pytest.mark.gpu
 def test_pool2_takes_the_large_frames_by_default(pkg, gpu, capfd):
     """pool2 = 1 (default): the pool-2 kernel renders frames of >= 32 M samples, the first kernel the smaller ones; the fuzz graphs
     with a second program run on both (tests/test_fuzz.py sets pool2 = 2 through RTG_POOL2)."""
