@@ -26,6 +26,11 @@ namespace rtg {
 #ifndef RT_P2_EXP
 #define RT_P2_EXP 0  // cost probes (WRONG pictures): bit 0 / 1 / 2 / 3 = hoist_eval without its primitive runs / media / wrapped Bvhs / random words
 #endif
+#ifndef RT_P2_SERVICE_PRIO
+#define RT_P2_SERVICE_PRIO 2  // (services at 2: 1.6 % faster than at the first kernel's 0 -- this kernel's waves wait more and issue less)
+#define RT_P2_BOX_PRIO RT_FULL_BOX_PRIO
+#define RT_P2_SLOW_PRIO RT_FULL_SLOW_PRIO
+#endif
 #ifndef RT_P2_PREFETCH
 #define RT_P2_PREFETCH 0  // 1: a finishing lane asks for its slot's line again so that the pass that takes the slot next finds it in the L2 -- measured 3 % SLOWER (r06d)
 #endif
@@ -146,6 +151,9 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   p2_u32x4 sdA = {0, 0, 0, 0}, sdB = sdA, sdC = sdA;  // the side record: items 0-1, 2-3, 4 + (ln u0, ln u1)
   [[maybe_unused]] uint32_t prefetch_sink = 0;  // (keeps the prefetch loads alive: stored at the end under a condition that never holds)
   Counts cnt = {0, 0, 0, 0};
+  // tests a pass makes for the rays it CREATES: kept apart from cnt -- the lane may hold a ray of its own at that moment, whose
+  // per-sample trace is the difference of cnt between its refill and its finish
+  Counts hoisted = {0, 0, 0, 0};
   uint32_t total_draws = 0;
   uint32_t* tr_out = nullptr;   // per-sample trace (instrumented variant; rt_pool.h): counters[30] = the table, counters[31] = per-slot accumulators
   uint32_t* tr_slot = nullptr;  // rows draws | aabb | prim of this wave's slots
@@ -314,7 +322,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
     const uint32_t n_fin = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(op == OP_END));
     const bool can_serve = t_count != 0u || s_count + n_fin >= 64u || (TEX && x_count + n_fin >= 64u) || e_count + n_fin >= 64u;
     if ((64u - n_busy >= tune.refill_min && can_serve) || n_busy == 0) {
-      __builtin_amdgcn_s_setprio(RT_FULL_SERVICE_PRIO);
+      __builtin_amdgcn_s_setprio(RT_P2_SERVICE_PRIO);
       if (COUNT) t_mark = RT_TICK();
       {  // (1) finish: what the walk found goes to the slot, the slot's id to S, X or E
         const bool fin = have_ray && op == OP_END;
@@ -344,7 +352,6 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
       // (2) shade: Material::scatter for 64 finished rays (color() loop body, lib.rs:73-97)
       auto shade_pass = [&](auto textured_tag) {
         constexpr bool TEXTURED = decltype(textured_tag)::value;
-        constexpr uint32_t PASS_FEAT = TEXTURED ? FEAT : (FEAT & ~FEAT_TEXTURE);
         uint32_t& count = TEXTURED ? x_count : s_count;
         const DevParams P = load_const(&lc->P);
         const ChunkMode cm = load_const(&lc->cm);
@@ -372,7 +379,8 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           uint4 mlo, mhi;
           if (mat_lds) mlo = s_mem[(mat_lds >> 4) + 2u * hm], mhi = s_mem[(mat_lds >> 4) + 2u * hm + 1u];
           else mlo = sc.mat[2 * hm], mhi = sc.mat[2 * hm + 1];
-          const V3 texval = material_texture<PASS_FEAT>(sc, mlo, mhi, p);  // = albedo / emission colour for constant textures
+          // (= albedo / emission colour for constant textures; checker / Perlin code only in passes over the X list)
+          const V3 texval = (TEX && TEXTURED) ? material_texture<FEAT>(sc, mlo, mhi, p) : material_texture<(FEAT & ~FEAT_TEXTURE)>(sc, mlo, mhi, p);
           const uint32_t pixel = (P.ny - 1u - row) * P.nx + x;
           SampleRng rng;
           rng.init(seed, pixel, s);
@@ -455,7 +463,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
               hoist_eval(id, p2_, nd, stime, seed, pixel, s, bounces + 1u, h_aabb, h_prim);
             }
             hoist_eval(id, p, nd, stime, seed, pixel, s, bounces + 1u, h_aabb, h_prim);
-            if (COUNT) cnt.aabb += h_aabb, cnt.prim += h_prim, cnt.rays++;
+            if (COUNT) hoisted.aabb += h_aabb, hoisted.prim += h_prim, cnt.rays++;
             if (COUNT && tr_slot) tr_slot[P2POOL + id] += h_aabb, tr_slot[2u * P2POOL + id] += h_prim;
           }
           if (ended) {  // both early returns of color() yield accum (lib.rs:90,94)
@@ -567,7 +575,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           SL_ST4(id, PS_STRENGTH, f2u(1.f), f2u(1.f), f2u(1.f), x | (row << 16));  // lib.rs:63
           uint32_t h_aabb, h_prim;
           hoist_eval(id, so, sd, stime, seed, y * P.nx + x, s, 1u, h_aabb, h_prim);
-          if (COUNT) cnt.aabb += h_aabb, cnt.prim += h_prim, cnt.rays++;
+          if (COUNT) hoisted.aabb += h_aabb, hoisted.prim += h_prim, cnt.rays++;
           if (COUNT && tr_slot) tr_slot[id] = rng.draws, tr_slot[P2POOL + id] = h_aabb, tr_slot[2u * P2POOL + id] = h_prim;
           te[t_count + lane_rank(m_live)] = (uint16_t)id;
         }
@@ -664,7 +672,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
       cur_lo = P2_LO(pc), cur_hi = P2_HI(pc);
       if (COUNT) t_refill += RT_TICK() - t_mark2;
       if (COUNT) t_serv += RT_TICK() - t_mark;
-      __builtin_amdgcn_s_setprio(RT_FULL_BOX_PRIO);
+      __builtin_amdgcn_s_setprio(RT_P2_BOX_PRIO);
       if (n_dead == P2POOL) {  // every slot retired
         if (load_const(&lc->cm.drain_share) != 0u) {  // leave when every wave of the workgroup has run dry and nothing waits to be adopted
           if (hungry && __builtin_amdgcn_readfirstlane(pool_lds_ld(ctl + DC_HUNGRY)) == n_waves &&
@@ -704,7 +712,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
       if (!(r_sph || r_pri || r_lst || r_psh)) {
         if (b_box == 0) break;  // (idle or finished lanes only)
         // ---- box run: tight loop, schedule re-evaluated once `box_leave` lanes have left the BOX state ----
-        __builtin_amdgcn_s_setprio(RT_FULL_BOX_PRIO);
+        __builtin_amdgcn_s_setprio(RT_P2_BOX_PRIO);
         const uint32_t n0 = (uint32_t)__builtin_popcountll(b_box);
         const uint32_t floor_lanes = n0 > tune.box_leave ? n0 - tune.box_leave : 0u;
         uint32_t n_now;
@@ -737,7 +745,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
       } else {
         // ---- slow pass ----
         if (COUNT) t_mark = RT_TICK();
-        __builtin_amdgcn_s_setprio(RT_FULL_SLOW_PRIO);
+        __builtin_amdgcn_s_setprio(RT_P2_SLOW_PRIO);
         const bool mine = (op == OP_SPHERE && r_sph) || ((op == OP_PRISM || op == OP_RECT) && r_pri) || (op == OP_LIST && r_lst) ||
                           ((op == OP_PUSH || op == OP_POP) && r_psh);
         if (COUNT) n_slow_it++, n_slow_lanes += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine));
@@ -858,8 +866,8 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   if (prefetch_sink == 0x9e3779b9u && total_work == 0xffffffffu) counters[63] = prefetch_sink;
 #endif
   if (COUNT) {
-    atomicAdd(&counters[0], (unsigned long long)cnt.aabb);
-    atomicAdd(&counters[1], (unsigned long long)cnt.prim);
+    atomicAdd(&counters[0], (unsigned long long)cnt.aabb + hoisted.aabb);
+    atomicAdd(&counters[1], (unsigned long long)cnt.prim + hoisted.prim);
     atomicAdd(&counters[2], (unsigned long long)cnt.shaded);
     atomicAdd(&counters[3], (unsigned long long)cnt.rays);
     atomicAdd(&counters[4], (unsigned long long)total_draws);

@@ -265,6 +265,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   uint32_t bmode = 0;                                // GENB: 0 = main walk, 1 / 2 = inside a boundary stream, query 1 / 2
   float t_lo = t_near, b_saved = 0.f, b_t1 = 0.f;    // GENB: lower end of the current range; the main walk's best; query 1's t
   Counts cnt = {0, 0, 0, 0};
+  uint32_t hoisted_prim = 0;  // primitive tests of the hoisted segment, made for rays a pass creates
   uint32_t total_draws = 0;
   uint32_t* tr_out = nullptr;  // per-sample trace of the instrumented variant (rt_pool.h)
   uint32_t tr_a0 = 0, tr_p0 = 0, tr_d = 0, tr_a = 0, tr_p = 0;  // the path's running draws / Aabb tests / primitive tests
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           float c_t;
           uint32_t c_pc, c_n;
           hoist_eval(so, sd, stime, c_t, c_pc, c_n);
-          if (COUNT) cnt.prim += c_n, trp += c_n;
+          if (COUNT) hoisted_prim += c_n, trp += c_n;  // (not cnt.prim: the lane may hold a ray of its own, whose trace is a difference of cnt)
           TQ_ST_F(TQ_SEG_T, i, c_t), TQ_ST_U(TQ_SEG_PC, i, c_pc);
           TQ_ST_F(TQ_O, i, so.x), TQ_ST_F(TQ_O + 1, i, so.y), TQ_ST_F(TQ_O + 2, i, so.z);
           TQ_ST_F(TQ_D, i, sd.x), TQ_ST_F(TQ_D + 1, i, sd.y), TQ_ST_F(TQ_D + 2, i, sd.z);
@@ -665,7 +666,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           float c_t;
           uint32_t c_pc, c_n;
           hoist_eval(so, sd, stime, c_t, c_pc, c_n);
-          if (COUNT) cnt.prim += c_n;
+          if (COUNT) hoisted_prim += c_n;
           TQ_ST_F(TQ_SEG_T, i, c_t), TQ_ST_U(TQ_SEG_PC, i, c_pc);
           TQ_ST_F(TQ_O, i, so.x), TQ_ST_F(TQ_O + 1, i, so.y), TQ_ST_F(TQ_O + 2, i, so.z);
           TQ_ST_F(TQ_D, i, sd.x), TQ_ST_F(TQ_D + 1, i, sd.y), TQ_ST_F(TQ_D + 2, i, sd.z);
@@ -813,7 +814,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
   RT_TL_DONE();
   if (COUNT) {
     atomicAdd(&counters[0], (unsigned long long)cnt.aabb);
-    atomicAdd(&counters[1], (unsigned long long)cnt.prim);
+    atomicAdd(&counters[1], (unsigned long long)cnt.prim + hoisted_prim);
     atomicAdd(&counters[2], (unsigned long long)cnt.shaded);
     atomicAdd(&counters[3], (unsigned long long)cnt.rays);
     atomicAdd(&counters[4], (unsigned long long)total_draws);
