@@ -84,7 +84,7 @@ struct P2Item {
 };
 constexpr uint32_t P2_MAX_ITEMS = 5;  // side record = 2 x 5 dwords + ln of the first two draws of the event's stream (media, object.rs:562)
 constexpr uint32_t P2_MAX_MEDIA = 2;
-constexpr uint32_t F_P2_DEAD_POP = 1u << 12;  // POP (second program): no BOX or primitive record follows in the walk -- the ray need not be restored
+constexpr uint32_t F_P2_DEAD_POP = 1u << 12;  // POP (second program): only POPs and OP_END follow in the walk -- the ray need not be restored
 struct P2Table {
   P2Item item[P2_MAX_ITEMS];
   uint32_t n_items, n_media, n_wrapped, pad;

@@ -616,13 +616,13 @@ bool SceneBuilder::flatten_pool2(const uint32_t* world, size_t n, FlatScene* out
     }
   }
   close_group();
-  // a POP behind which the walk meets no BOX and no primitive any more need not restore the ray
+  // a POP behind which the walk meets nothing but other POPs need not restore the ray
   {
     bool ray_needed = false;
     for (size_t r = w.lo.size(); r-- > 0;) {
       const uint32_t op = w.hi[r].w[3] & 0xffu;
       if (op == OP_POP && !ray_needed) w.hi[r].w[3] |= F_P2_DEAD_POP;
-      if (op != OP_POP && op != OP_LIST) ray_needed = true;
+      if (op != OP_POP) ray_needed = true;  // (an OP_LIST record too: a medium's commit takes |d|, a NaN candidate replays its run on the ray)
     }
   }
   push(&w, 0, 0, 0, 0, 0, 0, 0, OP_END);

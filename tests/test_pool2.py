@@ -52,6 +52,147 @@ def mixed_world(pkg, b, nx, ny):
     return world, cam, exp
 
 
+def random_p2_world(pkg, b, seed, nx, ny):
+    """A random world of the shape the second program takes: a list of plain primitives (spheres incl. moving ones, rects, prisms),
+    media over one primitive, Bvhs of primitives and once-wrapped such Bvhs (Translate, RotateY, Translate{RotateY}, Scale, FlipNormals,
+    LinearMove), at most five runs of list-level items and two media; every material and texture kind."""
+    S = pkg.scenes
+    rs = np.random.RandomState(seed)
+    b.set_perlin_tables(*pkg.small_rng.perlin_tables(int(rs.randint(1, 1 << 30))))
+
+    def f(lo, hi):
+        return float(np.float32(rs.uniform(lo, hi)))
+
+    def vec(lo, hi):
+        return S.v(f(lo, hi), f(lo, hi), f(lo, hi))
+
+    def texture():
+        k = rs.randint(0, 4)
+        if k <= 1:
+            return b.constant(vec(0.1, 0.95))
+        if k == 2:
+            return b.perlin(f(0.02, 0.3))
+        return b.checker(b.constant(vec(0.1, 0.9)), b.constant(vec(0.1, 0.9)))
+
+    def material(light=True):
+        k = rs.randint(0, 5 if light else 4)
+        if k == 0:
+            return b.lambertian(texture())
+        if k == 1:
+            return b.metal(vec(0.3, 0.95), f(0.0, 1.0))
+        if k == 2:
+            return b.dielectric(f(1.1, 2.0))
+        if k == 3:
+            return b.isotropic(texture())
+        return b.diffuse_light(texture(), f(0.5, 5.0))
+
+    def primitive(spread=260.0):
+        k = rs.randint(0, 5)
+        c = S.v(278.0, 278.0, 278.0) + S.f32(spread) * vec(-1.0, 1.0)
+        if k <= 1:
+            return b.translate(c, b.sphere(f(15, 70), material()))
+        if k == 2:
+            return b.translate(c, b.linear_move(b.sphere(f(15, 50), material()), vec(-40, 40)))
+        if k == 3:
+            a0, b0 = f(0, 400), f(0, 400)
+            r = b.rect(int(rs.randint(0, 3)), (a0, a0 + f(40, 250)), (b0, b0 + f(40, 250)), f(0, 555), material())
+            return b.flip_normals(r) if rs.rand() < 0.3 else r
+        p0 = c - S.v(40.0, 40.0, 40.0)
+        return b.rect_prism(p0, p0 + S.v(f(30, 120), f(30, 120), f(30, 120)), material())
+
+    def bvh():
+        return b.bvh([primitive() for _ in range(int(rs.randint(34, 70)))], (0.0, 1.0))  # (> 32 boxes: the pool kernels, not the lock-step one)
+
+    def wrapped():
+        k = rs.randint(0, 6)
+        inner = bvh()
+        if k == 0:
+            return b.translate(vec(-60, 60), inner)
+        if k == 1:
+            return b.rotate_y(f(-40, 40), inner)
+        if k == 2:
+            return b.translate(vec(-60, 60), b.rotate_y(f(-40, 40), inner))
+        if k == 3:
+            return b.scale(S.v(f(0.7, 1.3), f(0.7, 1.3), f(0.7, 1.3)), inner)
+        if k == 4:
+            return b.flip_normals(inner)
+        return b.translate(vec(-30, 30), b.linear_move(inner, vec(-20, 20)))
+
+    def medium():
+        bound = b.translate(S.v(278.0, 278.0, 278.0) + S.f32(150.0) * vec(-1.0, 1.0), b.sphere(f(60, 400), b.dielectric(1.5)))
+        if rs.rand() < 0.3:
+            bound = b.rect(int(rs.randint(0, 3)), (0.0, 555.0), (0.0, 555.0), f(100, 500), b.dielectric(1.5))  # a Rect never hits twice: no crossing
+        return b.constant_medium(bound, f(0.001, 0.02), b.isotropic(texture()))
+
+    world, items, media, have_bvh = [], 0, 0, False
+    last = None  # kind of the last list-level item run ("P" runs merge)
+    for _ in range(int(rs.randint(3, 9))):
+        k = rs.choice(["P", "P", "M", "B", "W"])
+        if k == "P":
+            if last != "P" and items >= 5:
+                continue
+            world.append(primitive(300.0))
+            items += last != "P"
+        elif k == "M":
+            if media >= 2 or items >= 5:
+                continue
+            world.append(medium())
+            media += 1
+            items += 1
+        elif k == "B":
+            world.append(bvh())
+            have_bvh = True
+        else:
+            if items >= 5:
+                continue
+            world.append(wrapped())
+            items += 1
+            have_bvh = True
+        last = k
+    if not have_bvh:
+        world.append(bvh())
+        last = "B"
+    if last == "P" or items < 5:
+        world.append(b.flip_normals(b.sphere(4000.0, b.diffuse_light(b.constant(S.v(0.6, 0.7, 0.9)), 0.8))))  # a sky dome: a plain primitive
+    cam, exp = S._cornell_camera(b.be, nx, ny)
+    return world, cam, exp
+
+
+N_P2_FUZZ = 32
+
+
+@pytest.mark.parametrize("seed", range(N_P2_FUZZ))
+def test_random_worlds_of_the_second_program_flatten(pkg, seed):
+    b = pkg.load().builder()
+    world, _, _ = random_p2_world(pkg, b, 7000 + seed, 32, 24)
+    w, items, n_media, n_wrapped = b.flatten_pool2(world)
+    assert len(w) != 0 and 1 <= len(items) <= 5 and n_media <= 2, (seed, len(w), items)
+    o = ops(w)
+    end = o.index(0)
+    assert all(x in (OP_BOX, OP_SPHERE, OP_RECT, OP_PRISM, OP_PUSH, OP_POP, OP_LIST, OP_EXT) for x in o[:end])   # the walk: Bvh streams, wrappers, list records
+    assert sum(int(w[i, 5]) for i, x in enumerate(o[:end]) if x == OP_LIST) == len(items)                        # every item is committed exactly once
+    assert o[:end].count(OP_PUSH) == o[:end].count(OP_POP) == n_wrapped
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(N_P2_FUZZ))
+def test_random_worlds_of_the_second_program_bit_exact(pkg, gpu, oracle, seed):
+    nx, ny, ns = 48, 32, 5
+    bo, bg = oracle.builder(), gpu.builder()
+    world_o, cam_o, _ = random_p2_world(pkg, bo, 7000 + seed, nx, ny)
+    world_g, cam_g, _ = random_p2_world(pkg, bg, 7000 + seed, nx, ny)
+    so, sg = bo.scene(world_o), bg.scene(world_g)
+    img_o, st_o = so.par_cast(cam_o, nx, ny, ns, stats=True)
+    sg.set_option("sync", 0)
+    for pool2 in (2, 0):
+        sg.set_option("pool2", pool2)
+        img_g, st_g = sg.par_cast(cam_g, nx, ny, ns, stats=True)
+        assert_bit_equal(img_g, img_o, "random second-program world %d, pool2=%d" % (seed, pool2))
+        for k in KEYS:
+            assert st_g[k] == st_o[k], (seed, pool2, k, st_g[k], st_o[k])
+        assert_bit_equal(sg.par_cast(cam_g, nx, ny, ns), img_o, "random second-program world %d, pool2=%d (timed variant)" % (seed, pool2))
+
+
 def book2_part(keep):
     def fn(pkg, b, nx, ny):
         world, cam, exp = pkg.scenes.book_final_scene(b, nx, ny, pkg.small_rng.SmallRng(0xDEADBEEF))

@@ -39,6 +39,7 @@ python tools/criterion_scene.py > $O/criterion_scene.txt 2>&1
 python tools/latency_probe.py > $O/latency_probe.txt 2>&1
 python tools/shard_time.py > $O/shard_time.txt 2>&1
 python tools/probe_book2_levers.py > $O/book2_levers.txt 2>&1
+python tools/stress_pool2.py 100000 300 > $O/stress_pool2.txt 2>&1
 python tools/probe_pool2.py 800 800 100 > $O/pool_vs_pool2.txt 2>&1
 python tools/probe_pool2.py 800 800 1000 --only all >> $O/pool_vs_pool2.txt 2>&1
 RTG_POOL2=0 python tools/tail_probe.py book2 800 800 > $O/tail_probe_book2_first_kernel.txt 2>&1
