@@ -54,7 +54,8 @@ sc.set_option("pool2", 2)
 for k, v in base.items():
     sc.set_option(k, int(v))
 print("pool 2, base %s: %.2f ms" % (base, timed()), flush=True)
-DEFAULTS = dict(p2_refill=24, p2_box_leave=48, p2_park=40, p2_sphere=4, p2_prism=8, p2_list=24, p2_push=2)
+DEFAULTS = dict(p2_refill=24, p2_box_leave=48, p2_park=40, p2_sphere=4, p2_prism=8, p2_list=24, p2_push=2,
+                lpt=2, lpt_deep=4, lpt_shift=0, lpt_phase1=0, drain_share=1)
 DEFAULTS.update({k: int(v) for k, v in base.items()})
 for name, vals in params:
     row = []
