@@ -81,6 +81,10 @@ struct Pool2Tuning {
 typedef uint32_t p2_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t p2_u32x3 __attribute__((ext_vector_type(3)));
 typedef uint32_t p2_u32x2 __attribute__((ext_vector_type(2)));
+RT_DEV uint4 p2_record(uint32_t lds_addr) {  // 16 bytes at a 16-byte aligned absolute LDS address
+  const p2_u32x4 v = RT_AS3(p2_u32x4, lds_addr);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
 
 template <bool TEX, bool COUNT>
 __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_pool2(DevScene sc, const LaunchConsts* __restrict__ lc, float* __restrict__ out,
@@ -96,7 +100,6 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
     s_mem[2u * i] = sc.lo[i];
     s_mem[2u * i + 1u] = h;
   }
-  const char* s_bytes = reinterpret_cast<const char*>(s_mem);
   uint32_t* ctl = reinterpret_cast<uint32_t*>(s_mem + 2u * n_prog);
   if (threadIdx.x < DC_WORDS) ctl[threadIdx.x] = 0u;
   uint32_t* s_table = ctl + DC_WORDS;  // P2Table, as words
@@ -119,8 +122,11 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
 #endif
   __syncthreads();
 
-#define P2_LO(pc_) (*reinterpret_cast<const uint4*>(s_bytes + (pc_)))
-#define P2_HI(pc_) (*reinterpret_cast<const uint4*>(s_bytes + (pc_) + 16u))
+  // A record's byte offset IS its LDS address: the kernel has no static __shared__ data, so the dynamic segment starts at 0 (checked
+  // here) -- as `s_bytes + pc` every record fetch carried a `v_add_u32 v, 0, pc` for the segment's base.
+  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)s_mem != 0u) __builtin_trap();
+#define P2_LO(pc_) p2_record(pc_)
+#define P2_HI(pc_) p2_record((pc_) + 16u)
 #define SL_OFF(id_, f_) ((id_) * P2_SLOT_BYTES + (f_))
 #define SL_LD1(id_, f_) __builtin_amdgcn_raw_buffer_load_b32(qr, SL_OFF(id_, f_), 0, 0)
 #define SL_LD2(id_, f_) __builtin_amdgcn_raw_buffer_load_b64(qr, SL_OFF(id_, f_), 0, 0)
@@ -143,10 +149,11 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
 
   // ---- per-lane traversal state ---------------------------------------------------------------
   bool have_ray = false;
-  uint32_t my_slot = 0;
   V3 o = mk(0.f, 0.f, 0.f), d = o, inv = o;
   float time = 0.f, best = F32_MAX;
-  uint32_t pc = 0, hmat = NO_HIT, ev = 0;
+  uint32_t pc = 0, hmat = NO_HIT;
+  uint32_t ev = 0;  // medium draws the walk has made (low byte) | the lane's slot << 8: one register (a thirteenth live across the passes was spilled)
+#define my_slot (ev >> 8)
   uint4 cur_lo = make_uint4(0, 0, 0, 0), cur_hi = make_uint4(0, 0, 0, OP_END);
   p2_u32x4 sdA = {0, 0, 0, 0}, sdB = sdA, sdC = sdA;  // the side record: items 0-1, 2-3, 4 + (ln u0, ln u1)
   [[maybe_unused]] uint32_t prefetch_sink = 0;  // (keeps the prefetch loads alive: stored at the end under a condition that never holds)
@@ -336,8 +343,8 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
           // waves is ~14 MB): ask for it now -- one dword, nobody waits for it -- so that the line is back when the pass starts
           prefetch_sink ^= SL_LD1(my_slot, to_e ? PS_SAMPLE : PS_O);
 #endif
-          if (!to_e) SL_ST3(my_slot, PS_BEST, f2u(best), hmat, ev);
-          if (COUNT && tr_slot) tr_slot[my_slot] += ev, tr_slot[P2POOL + my_slot] += cnt.aabb - tr_a0, tr_slot[2u * P2POOL + my_slot] += cnt.prim - tr_p0;
+          if (!to_e) SL_ST3(my_slot, PS_BEST, f2u(best), hmat, ev & 0xffu);
+          if (COUNT && tr_slot) tr_slot[my_slot] += ev & 0xffu, tr_slot[P2POOL + my_slot] += cnt.aabb - tr_a0, tr_slot[2u * P2POOL + my_slot] += cnt.prim - tr_p0;
           if (to_e) te[P2POOL - 1u - (e_count + lane_rank(m_e))] = (uint16_t)(my_slot | E_MISS);
           else if (to_x) sx[P2POOL - 1u - (x_count + lane_rank(m_x))] = (uint16_t)my_slot;
           else sx[s_count + lane_rank(m_s)] = (uint16_t)my_slot;
@@ -647,7 +654,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
         if (got) {
           const uint32_t r = lane_rank(m_idle);
           if (!have_ray && r < got) {
-            my_slot = te[t_count - 1u - r];
+            ev = (uint32_t)te[t_count - 1u - r] << 8;
             const p2_u32x4 a0 = SL_LD4(my_slot, PS_O);
             const p2_u32x3 a1 = SL_LD3(my_slot, PS_D);
 #if !RT_P2_RELOAD_SIDE
@@ -655,7 +662,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
 #endif
             o = mk(u2f(a0.x), u2f(a0.y), u2f(a0.z)), time = u2f(a0.w);
             d = mk(u2f(a1.x), u2f(a1.y), u2f(a1.z));
-            pc = 0, best = F32_MAX, hmat = NO_HIT, ev = 0;
+            pc = 0, best = F32_MAX, hmat = NO_HIT;
             if (COUNT) tr_a0 = cnt.aabb, tr_p0 = cnt.prim;
             have_ray = true;
           }
@@ -823,7 +830,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
                   const uint4 m_lo = P2_LO(ia), m_hi = P2_HI(ia);
                   const float len = vlen(d);
                   const float distance_inside = (t2 - t1) * len;
-                  const float ln_u = u2f(ev == 0u ? sdC.z : sdC.w);  // ln of draw `ev` of the event's stream (evaluated when the ray was created)
+                  const float ln_u = u2f((ev & 0xffu) == 0u ? sdC.z : sdC.w);  // ln of draw `ev` of the event's stream (evaluated when the ray was created)
                   const float hit_distance = -u2f(m_lo.y) * ln_u;    // -(1. / density) * rng().ln(), object.rs:562 (m_lo.y = 1 / density)
                   ev++;
                   if (COUNT) total_draws++;
@@ -898,6 +905,7 @@ __global__ __launch_bounds__(TEX ? RT_FULL_TEX_THREADS : 1024) void render_full_
 #undef SL_ST3
 #undef SL_ST4
 #undef SL_ST_SIDE
+#undef my_slot
 }
 
 }  // namespace rtg
